@@ -1,0 +1,45 @@
+# Builds everything in-tree (the .so files travel to the GPU box with the snapshot).
+#   libtrt_hip.so   — the C-ABI hot path (include/trt.h), HIP for gfx950
+#   libtrt_host.so  — loaders / BVH / PNG (include/trt_host.h), plain C++
+#   tinyrt          — CLI: loaders -> render() -> PNG (the reference's main())
+#   oracle/liboracle.so — CPU restatement used by tests/ and bench.py only
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+PKG := tinyraytracing_amd
+OUT := $(PKG)/lib
+
+# Bit-parity rule (include/trt_prims.h): no FP contraction on either side;
+# FMA only where the source says fmaf.  x86-64-v3 = AVX2 + hardware FMA.
+CPU_FP := -ffp-contract=off -march=x86-64-v3
+CXXFLAGS := -O2 -g0 -std=c++17 -fPIC -Wall -Wextra $(CPU_FP) -Iinclude -I$(PKG)/host
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
+            -Wall -Wextra -Wno-unused-parameter -Iinclude -I$(PKG)/csrc
+
+HOST_SRC := $(PKG)/host/scene.cpp $(PKG)/host/bvh.cpp $(PKG)/host/synth.cpp $(PKG)/host/image_out.cpp $(PKG)/host/capi.cpp
+HOST_HDR := $(wildcard $(PKG)/host/*.h) include/trt.h include/trt_host.h include/trt_prims.h
+HIP_SRC := $(PKG)/csrc/trt_api.hip
+HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h
+
+.PHONY: all host hip oracle cli clean
+all: host hip oracle cli
+
+host: $(OUT)/libtrt_host.so
+hip: $(OUT)/libtrt_hip.so
+cli: $(OUT)/tinyrt
+oracle:
+	$(MAKE) -C oracle
+
+$(OUT)/libtrt_host.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(OUT)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC)
+
+$(OUT)/libtrt_hip.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+$(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so
+	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -Wl,-rpath,'$$ORIGIN'
+
+clean:
+	rm -rf $(OUT)
+	$(MAKE) -C oracle clean

@@ -1,0 +1,217 @@
+/*
+ * trt.h — C-ABI of the MI355X path-tracing hot path (libtrt_hip.so).
+ *
+ * This is the drop-in boundary for the per-pixel Monte-Carlo inner loop of
+ * TinyRayTracing.  The reference has no FFI; its "render entry point" is the
+ * body of main() (RayTracingOnCPU/main.cpp:79-113: the OpenMP sample/pixel
+ * loop calling Camera::getRay camera.cpp:19-28, traverseBVH bvh.cpp:146-175
+ * and shade pathTracing.cpp:3-102).  Every entry point below replaces a piece
+ * of that loop; the citation says which.
+ *
+ * Plain C: pointers + sizes only, no C++/torch types.  All functions return 0
+ * on success and a non-zero TRT_E* code on failure; the message is available
+ * from trt_last_error() (thread-local).  The library never calls exit()
+ * (the reference exit()s from its loaders, scene.cpp:10,64,122, and from
+ * Sample(), pathTracing.cpp:129).
+ */
+#ifndef TRT_H
+#define TRT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRT_ABI_VERSION 1
+
+/* error codes */
+#define TRT_OK 0
+#define TRT_EINVAL 1   /* bad argument / inconsistent scene */
+#define TRT_EHIP 2     /* HIP runtime error */
+#define TRT_ENOMEM 3   /* device or host allocation failed */
+#define TRT_ENODEV 4   /* no usable gfx950 device */
+
+/* Reference constants (pathtracing.h:11-12, bvh.h:5, ray.h:5-8, bvh.cpp:185,189). */
+#define TRT_PI 3.1415926f
+#define TRT_P_RR 0.8f
+#define TRT_INF 114514.0f
+#define TRT_T_MIN 0.0005f
+#define TRT_PARALLEL_EPS 0.00001f
+#define TRT_RAY_DIFFUSE 0
+#define TRT_RAY_SPECULAR 1
+#define TRT_RAY_TRANSMISSION 2
+#define TRT_RAY_INVALID 3
+
+/* ---- flat scene (what main.cpp hands the loop: scene.triangles in post-BVH
+ *      order, scene.materials, scene.lights, scene.camera, root) ------------ */
+
+/* BVH2 inner node, 64 B.  Replaces BVHNode (bvh.h:16-22: two pointers, index,
+ * num, AA, BB).  The two children's padded boxes (bvh.cpp:31-40) live in the
+ * parent so one 64-B fetch decides both descents (bvh.cpp:156-166).
+ * child refs: bit31 = 0 -> index of an inner node;
+ *             bit31 = 1 -> leaf: bits 30..27 = triangle count (0..15),
+ *                                bits 26..0  = first triangle (post-BVH order). */
+typedef struct trt_bvh_node {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t child0, child1;
+    uint32_t reserved[2];
+} trt_bvh_node;
+
+#define TRT_LEAF_BIT 0x80000000u
+#define TRT_LEAF_COUNT(ref) (((ref) >> 27) & 15u)
+#define TRT_LEAF_FIRST(ref) ((ref) & 0x07FFFFFFu)
+#define TRT_MAKE_LEAF(first, count) (TRT_LEAF_BIT | ((uint32_t)(count) << 27) | (uint32_t)(first))
+#define TRT_MAX_LEAF_TRIS 15u
+#define TRT_MAX_TRIS 0x07FFFFFFu
+
+/* Material (material.h:11-33) with the light's radiance folded in
+ * (scene.cpp:50-52).  tex = -1 when map_Kd == "". */
+typedef struct trt_material {
+    float Kd[3], Ks[3], Tr[3];
+    float Ns, Ni;
+    float radiance[3];
+    int32_t is_emissive;
+    int32_t tex;
+} trt_material;
+
+/* One <light> element, XML order (scene.cpp:25-54).  area = Material::area
+ * accumulated in readobj (scene.cpp:201-203). */
+typedef struct trt_light {
+    int32_t mat;          /* material id of mtlname */
+    float radiance[3];
+    float area;           /* total area A_l of this light's triangles */
+    uint32_t tri_first;   /* into light_tris */
+    uint32_t tri_count;
+} trt_light;
+
+/* Copy of an emissive triangle kept per light material for sampling
+ * (Material::triangles, scene.cpp:204); cum_area = Triangle::area, the
+ * running total at the time it was appended (scene.cpp:203). */
+typedef struct trt_light_tri {
+    float v[3][3];
+    float vn[3][3];
+    float cum_area;
+} trt_light_tri;
+
+/* 8-bit RGB texture, row-major, row 0 first as stored in the file (the
+ * reference indexes cv::Mat rows directly, pathTracing.cpp:22-25). */
+typedef struct trt_texture {
+    int32_t width, height;
+    const uint8_t* rgb;
+} trt_texture;
+
+/* Camera after setCamera() (camera.cpp:3-17). */
+typedef struct trt_camera {
+    float eye[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+} trt_camera;
+
+typedef struct trt_scene {
+    uint32_t n_tris;
+    const float* tri_v;      /* [n_tris][3][3]  Triangle::v  (triangle.h:14), post-BVH order */
+    const float* tri_vn;     /* [n_tris][3][3]  Triangle::vn (triangle.h:15) */
+    const float* tri_vt;     /* [n_tris][3][2]  Triangle::vt (triangle.h:16) */
+    const int32_t* tri_mat;  /* [n_tris] material id (replaces Triangle::mtl_name) */
+    uint32_t n_nodes;
+    const trt_bvh_node* nodes; /* nodes[0] is the root; n_nodes >= 1 */
+    uint32_t bvh_depth;      /* max number of inner nodes on a root->leaf path */
+    uint32_t n_materials;
+    const trt_material* materials;
+    uint32_t n_lights;
+    const trt_light* lights;
+    uint32_t n_light_tris;
+    const trt_light_tri* light_tris;
+    uint32_t n_textures;
+    const trt_texture* textures;
+    trt_camera camera;
+} trt_scene;
+
+/* ---- render parameters ---------------------------------------------------- */
+
+#define TRT_FLAG_TIMING 1u   /* per-kernel hipEvent timing into trt_stats */
+#define TRT_FLAG_COUNT 2u    /* count inner-node visits / triangle tests (stats kernels) */
+
+typedef struct trt_params {
+    int32_t width, height;   /* full image size (scene.img_width/height, scene.cpp:13-14) */
+    int32_t spp;             /* SAMPLE (main.cpp:13,55) */
+    uint32_t seed;           /* counter-RNG seed; stream = (seed, pixel y*width+x, sample) */
+    /* tile rectangle [x0,x1) x [y0,y1) of the full image rendered by this call */
+    int32_t x0, y0, x1, y1;
+    /* row interleave for multi-GPU image tiling: only rows y (inside the tile)
+     * with ((y / row_block) % row_mod) == row_rem are rendered; output rows are
+     * packed in increasing y.  row_mod <= 1 renders every row. */
+    int32_t row_block, row_mod, row_rem;
+    int32_t max_depth;       /* 0 = unbounded like the reference (pathTracing.cpp:78-99) */
+    uint32_t flags;
+    uint64_t mem_budget;     /* bytes of HBM for path/queue state; 0 = default */
+} trt_params;
+
+#define TRT_MAX_KERNELS 8
+enum {
+    TRT_K_GEN_PRIMARY = 0,
+    TRT_K_TRACE_CLOSEST = 1,
+    TRT_K_SHADE = 2,
+    TRT_K_TRACE_SHADOW = 3,
+    TRT_K_RESOLVE = 4
+};
+
+typedef struct trt_stats {
+    uint64_t rays_camera;       /* primary rays traced */
+    uint64_t rays_shadow;       /* NEE closest-hit rays traced (pathTracing.cpp:54) */
+    uint64_t rays_indirect;     /* valid extension rays traced (pathTracing.cpp:81, INVALID excluded) */
+    uint64_t shaded_hits;       /* path vertices that reached shade() */
+    uint64_t inner_visits[2];   /* [closest, shadow] inner nodes whose two child boxes were tested (TRT_FLAG_COUNT) */
+    uint64_t tri_tests[2];      /* [closest, shadow] triangle tests (TRT_FLAG_COUNT) */
+    uint64_t launches[TRT_MAX_KERNELS];
+    double kernel_ms[TRT_MAX_KERNELS]; /* summed launch durations (TRT_FLAG_TIMING) */
+    double render_ms;           /* first gen_primary launch -> last resolve, device time */
+    uint32_t passes;            /* sample chunks the render was split into */
+    uint32_t max_bounces;       /* deepest path vertex index reached */
+    uint64_t rows_rendered;     /* rows in the packed output */
+} trt_stats;
+
+typedef struct trt_handle trt_handle;
+
+/* Number of image rows a trt_params selects (tile rows passing the interleave). */
+int trt_rows_selected(const trt_params* p);
+
+/* Upload the flat scene to HBM on `device` (HIP ordinal) and build the
+ * device-side 48-B Moller-Trumbore triangle records and 64-B shading records.
+ * Replaces nothing the reference times; it is the hand-over of scene.triangles /
+ * root to the loop at main.cpp:76-81. */
+int trt_create(const trt_scene* scene, int device, trt_handle** out);
+
+/* render(): replaces main.cpp:79-113.  Renders p->spp samples of every
+ * selected pixel and writes the averaged linear radiance, RGB interleaved,
+ * row-major, rows packed (see row_block), as float into a HOST buffer of
+ * rows_selected * (x1-x0) * 3 floats.  `stats` may be NULL. */
+int trt_render(trt_handle* h, const trt_params* p, float* out_rgb_host, trt_stats* stats);
+
+/* Same, but out_rgb is DEVICE memory on the handle's device and all work is
+ * enqueued on `hip_stream` (a hipStream_t, or NULL for the default stream);
+ * returns after the stream has been synchronised. */
+int trt_render_device(trt_handle* h, const trt_params* p, float* out_rgb_dev,
+                      void* hip_stream, trt_stats* stats);
+
+/* traverseBVH (bvh.cpp:146-175) on a batch of n rays given as HOST arrays
+ * org[n][3], dir[n][3].  Outputs (host): t[n] (TRT_INF on miss), tri[n]
+ * (post-BVH triangle index, -1 on miss), uv[n][2] (barycentrics of v1,v2).
+ * `stats` (optional) receives inner_visits[0]/tri_tests[0] and kernel_ms. */
+int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* dir,
+                      float* t, int32_t* tri, float* uv, trt_stats* stats);
+
+void trt_destroy(trt_handle* h);
+
+const char* trt_last_error(void);
+
+int trt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRT_H */

@@ -1,0 +1,789 @@
+/*
+ * oracle.cpp — CPU restatement of TinyRayTracing's per-pixel path-tracing loop.
+ *
+ * TEST INFRASTRUCTURE ONLY: the checker for the HIP path and the "port" CPU
+ * baseline of bench.py.  Never linked into or called from the product.
+ *
+ * What it restates (file:line under /root/reference/RayTracingOnCPU/):
+ *   main.cpp:80-113        sample/pixel loop, pixel -> (s,t), jitter, accumulation
+ *   camera.cpp:19-28       Camera::getRay
+ *   bvh.cpp:146-175        traverseBVH   (recursive, both children, no culling)
+ *   bvh.cpp:177-209        interactTriangle
+ *   bvh.cpp:211-229        interactBVHNode (leaf scan + emissive tie rule)
+ *   bvh.cpp:231-245        interactAABB
+ *   bvh.cpp:16-144         buildBVH (oracle_build_bvh)
+ *   triangle.cpp:12-29     findBaryCor  -> the barycentrics of the hit
+ *   pathTracing.cpp:3-102  shade        (ORACLE_MODE_RECURSIVE literally; ITERATIVE as
+ *                                        L += beta*L_dir, beta *= w/P_RR — SURVEY.md §8 a13)
+ *   pathTracing.cpp:104-109 RR, :111-145 Sample, :147-209 nextRay
+ *
+ * PARITY UNPINNED.  The reference ships no tests, golden vectors or known-answer
+ * values for this path, cannot be compiled here (glm, Eigen, tinyxml2, OpenCV
+ * are absent; fopen_s is MSVC-only) and has no per-pixel RNG to reproduce
+ * (SURVEY.md §0.5, §0.7, §8c).  The oracle is therefore pinned only by its own
+ * analytic known-answer tests (tests/test_oracle_kat.py) and by loose image
+ * statistics of the reference's saved PNGs.
+ *
+ * Arithmetic.  fp32 throughout, compiled with -ffp-contract=off so that every
+ * operation is the one written.  Where the reference leaves a choice the
+ * formulation is the one SURVEY.md §8a fixes for both sides:
+ *   - ray/triangle: Moller-Trumbore with the reference's decisions mapped onto it
+ *     (|N.d| < 1e-5  <=>  |det| < 1e-5*|e1 x e2|;  t < 0.0005 miss;  strictly inside
+ *     <=> u>0, v>0, u+v<1), written with explicit fmaf in a fixed order;
+ *   - barycentrics of the hit = (1-u-v, u, v) from that test;
+ *   - sin/cos/pow and the random stream come from include/trt_prims.h.
+ * Scalars the reference keeps in double (RR, Fresnel, lobe selection, light
+ * point weights) are evaluated in fp32 here, except the pixel -> (s,t) mapping
+ * and the texel addressing, which stay in double as in the reference.
+ * Draw order per camera sample: jitter x, jitter y; per vertex:
+ * for each light {CDF; if a triangle is selected: r1,r2,r3}; RR; [Fresnel];
+ * [lobe]; [phi, theta].
+ */
+#include "oracle.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "trt_prims.h"
+
+namespace {
+
+// ---------------------------------------------------------------- vectors ----
+// Evaluation order is glm's: dot = (x+y)+z, normalize = v * (1/sqrt(dot(v,v))).
+struct V3 {
+    float x, y, z;
+};
+inline V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 ld(const float* p) { return V3{p[0], p[1], p[2]}; }
+inline V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+inline float length(V3 a) { return sqrtf(dot(a, a)); }
+inline V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+inline float gmin(float a, float b) { return (b < a) ? b : a; }  // glm::min
+inline float gmax(float a, float b) { return (a < b) ? b : a; }  // glm::max
+// glm::reflect: I - N * dot(N, I) * 2
+inline V3 reflect(V3 I, V3 N) { return I - (N * dot(N, I)) * 2.0f; }
+// glm::refract: k = 1 - eta^2 (1 - (N.I)^2); k < 0 -> 0, else eta*I - (eta*(N.I) + sqrt(k))*N
+inline V3 refract(V3 I, V3 N, float eta)
+{
+    const float dn = dot(N, I);
+    const float k = 1.0f - eta * eta * (1.0f - dn * dn);
+    if (k < 0.0f) return mk(0.f, 0.f, 0.f);
+    return I * eta - N * (eta * dn + sqrtf(k));
+}
+
+// ------------------------------------------------------------ scene views ----
+struct Tri {
+    V3 v0, e1, e2;
+    float tol;  // 1e-5 * |e1 x e2|: the parallel cut of bvh.cpp:185 in Moller-Trumbore terms
+};
+
+struct SceneView {
+    const trt_scene* s;
+    std::vector<Tri> tris;
+    explicit SceneView(const trt_scene* sc) : s(sc)
+    {
+        tris.resize(sc->n_tris);
+        for (uint32_t i = 0; i < sc->n_tris; ++i) {
+            const float* p = sc->tri_v + (size_t)i * 9;
+            Tri t;
+            t.v0 = ld(p);
+            t.e1 = ld(p + 3) - t.v0;
+            t.e2 = ld(p + 6) - t.v0;
+            const V3 g = cross(t.e1, t.e2);
+            t.tol = TRT_PARALLEL_EPS * sqrtf(dot(g, g));
+            tris[i] = t;
+        }
+    }
+    bool emissive(int32_t tri) const { return s->materials[s->tri_mat[tri]].is_emissive != 0; }
+};
+
+struct Hit {
+    float t = TRT_INF;  // HitRecord::distance default (bvh.h:10)
+    int32_t tri = -1;   // -1 == !is_hit
+    float u = 0.f, v = 0.f;
+};
+
+struct Counters {
+    uint64_t rays[3] = {0, 0, 0};  // camera, shadow, indirect
+    uint64_t shaded = 0;
+    uint64_t inner[2] = {0, 0}, tests[2] = {0, 0};
+    uint32_t max_bounces = 0;
+    void add(const Counters& o)
+    {
+        for (int i = 0; i < 3; ++i) rays[i] += o.rays[i];
+        shaded += o.shaded;
+        for (int i = 0; i < 2; ++i) { inner[i] += o.inner[i]; tests[i] += o.tests[i]; }
+        max_bounces = std::max(max_bounces, o.max_bounces);
+    }
+};
+
+// ------------------------------------------------- interactTriangle (a6) ----
+// bvh.cpp:177-209 on the Moller-Trumbore form; see the header comment.
+inline bool triTest(const Tri& T, V3 o, V3 d, float& t_out, float& u_out, float& v_out)
+{
+    const float px = fmaf(d.y, T.e2.z, -(d.z * T.e2.y));
+    const float py = fmaf(d.z, T.e2.x, -(d.x * T.e2.z));
+    const float pz = fmaf(d.x, T.e2.y, -(d.y * T.e2.x));
+    float det = fmaf(T.e1.z, pz, fmaf(T.e1.y, py, T.e1.x * px));
+    if (fabsf(det) < T.tol) return false;                      // bvh.cpp:185
+    const float tx = o.x - T.v0.x, ty = o.y - T.v0.y, tz = o.z - T.v0.z;
+    float un = fmaf(tz, pz, fmaf(ty, py, tx * px));
+    const float qx = fmaf(ty, T.e1.z, -(tz * T.e1.y));
+    const float qy = fmaf(tz, T.e1.x, -(tx * T.e1.z));
+    const float qz = fmaf(tx, T.e1.y, -(ty * T.e1.x));
+    float vn = fmaf(d.z, qz, fmaf(d.y, qy, d.x * qx));
+    float tn = fmaf(T.e2.z, qz, fmaf(T.e2.y, qy, T.e2.x * qx));
+    if (det < 0.0f) { det = -det; un = -un; vn = -vn; tn = -tn; }
+    if (!(un > 0.0f && vn > 0.0f && (un + vn) < det)) return false;  // bvh.cpp:196-198, strict
+    const float t = tn / det;
+    if (t < TRT_T_MIN) return false;                           // bvh.cpp:189
+    t_out = t;
+    u_out = un / det;
+    v_out = vn / det;
+    return true;
+}
+
+// ----------------------------------------------------- interactAABB (a4) ----
+// bvh.cpp:231-245.  inv = 1/d is formed in double there and narrowed; for a
+// binary32 d that equals the correctly rounded fp32 quotient.
+inline float aabb(const float* lo, const float* hi, V3 o, V3 inv)
+{
+    const float inx = (hi[0] - o.x) * inv.x, iny = (hi[1] - o.y) * inv.y, inz = (hi[2] - o.z) * inv.z;
+    const float outx = (lo[0] - o.x) * inv.x, outy = (lo[1] - o.y) * inv.y, outz = (lo[2] - o.z) * inv.z;
+    const float tmaxx = gmax(inx, outx), tmaxy = gmax(iny, outy), tmaxz = gmax(inz, outz);
+    const float tminx = gmin(inx, outx), tminy = gmin(iny, outy), tminz = gmin(inz, outz);
+    const float t1 = gmin(tmaxx, gmin(tmaxy, tmaxz));
+    const float t0 = gmax(tminx, gmax(tminy, tminz));
+    return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
+
+struct Tracer {
+    const SceneView& sv;
+    Counters* cnt;
+    int kind;  // 0 closest, 1 shadow (only for the counters)
+
+    // interactBVHNode (bvh.cpp:211-229): scan in index order; replace when
+    // strictly nearer, or equally near and emissive.
+    Hit leafScan(uint32_t first, uint32_t count, V3 o, V3 d) const
+    {
+        Hit res;
+        for (uint32_t i = first; i < first + count; ++i) {
+            float t, u, v;
+            if (cnt) cnt->tests[kind]++;
+            if (!triTest(sv.tris[i], o, d, t, u, v)) continue;
+            if ((t == res.t && sv.emissive((int32_t)i)) || t < res.t) {
+                res.t = t;
+                res.tri = (int32_t)i;
+                res.u = u;
+                res.v = v;
+            }
+        }
+        return res;
+    }
+
+    // traverseBVH (bvh.cpp:146-175)
+    Hit traverse(uint32_t ref, V3 o, V3 d, V3 inv) const
+    {
+        if (ref & TRT_LEAF_BIT) return leafScan(TRT_LEAF_FIRST(ref), TRT_LEAF_COUNT(ref), o, d);
+        const trt_bvh_node& n = sv.s->nodes[ref];
+        if (cnt) cnt->inner[kind]++;
+        const float d1 = aabb(n.lo0, n.hi0, o, inv);
+        const float d2 = aabb(n.lo1, n.hi1, o, inv);
+        Hit r1, r2;
+        if (d1 > 0) r1 = traverse(n.child0, o, d, inv);
+        if (d2 > 0) r2 = traverse(n.child1, o, d, inv);
+        if (r1.t == r2.t) return (r1.tri >= 0 && sv.emissive(r1.tri)) ? r1 : r2;  // bvh.cpp:168-172
+        return r1.t < r2.t ? r1 : r2;
+    }
+
+    Hit closest(V3 o, V3 d) const
+    {
+        const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        return traverse(0u, o, d, inv);
+    }
+
+    Hit brute(V3 o, V3 d) const { return leafScan(0, sv.s->n_tris, o, d); }
+};
+
+// ------------------------------------------------------------- RNG stream ----
+struct Stream {
+    trt_rng_key key;
+    uint32_t ctr;
+    float next() { return trt_rng_uniform(key, ctr++); }
+};
+
+// ----------------------------------------------------------- Sample (a12) ----
+// pathTracing.cpp:111-145: phi is drawn first, then theta.
+inline V3 sampleDir(V3 a, int ray_type, float Ns, float u_phi, float u_theta)
+{
+    float c, s;
+    trt_sincos2pi(u_phi, &c, &s);
+    float sin_t, cos_t;
+    if (ray_type == TRT_RAY_DIFFUSE) {  // theta = asin(sqrt(u))
+        sin_t = sqrtf(u_theta);
+        cos_t = sqrtf(1.0f - u_theta);
+    } else {  // theta = acos(u^(1/(Ns+1)))
+        cos_t = trt_pow01(u_theta, 1.0f / (Ns + 1.0f));
+        const float s2 = 1.0f - cos_t * cos_t;
+        sin_t = sqrtf(s2 > 0.0f ? s2 : 0.0f);
+    }
+    const V3 local = mk(sin_t * c, cos_t, sin_t * s);
+    V3 front;
+    if (fabsf(a.x) > fabsf(a.y)) front = normalize(mk(a.z, 0.0f, -a.x));
+    else front = normalize(mk(0.0f, -a.z, a.y));
+    const V3 right = cross(a, front);
+    return normalize((right * local.x + a * local.y) + front * local.z);
+}
+
+// ---------------------------------------------------------- nextRay (a11) ----
+// pathTracing.cpp:147-209.  `I` is the incoming direction (= -wi).
+inline int nextRay(const trt_material& m, V3 pn, V3 I, Stream& rng, V3& out)
+{
+    if (m.Ni > 1.0f) {
+        const float cos_in = dot(I, pn);
+        V3 n;
+        float n1, n2;
+        if (cos_in > 0.0f) { n = -pn; n1 = m.Ni; n2 = 1.0f; }
+        else { n = pn; n1 = 1.0f; n2 = m.Ni; }
+        const float q = (n1 - n2) / (n1 + n2);
+        const float rf0 = q * q;
+        const float x = 1.0f - fabsf(cos_in);
+        const float x2 = x * x;
+        const float fresnel = rf0 + (1.0f - rf0) * ((x2 * x2) * x);
+        if (fresnel < rng.next()) {
+            const V3 T = refract(I, n, n1 / n2);
+            if (T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) { out = T; return TRT_RAY_TRANSMISSION; }
+            out = reflect(I, n);  // total internal reflection
+            return TRT_RAY_SPECULAR;
+        }
+    }
+    const float Kd_len = length(ld(m.Kd)), Ks_len = length(ld(m.Ks));
+    const float kd = Kd_len / (Kd_len + Ks_len), ks = Ks_len / (Kd_len + Ks_len);
+    const float p = rng.next();
+    if (p < kd) {
+        const float u_phi = rng.next(), u_theta = rng.next();
+        out = sampleDir(pn, TRT_RAY_DIFFUSE, m.Ns, u_phi, u_theta);
+        return TRT_RAY_DIFFUSE;
+    }
+    if (m.Ns > 1.0f && p < kd + ks) {
+        const float u_phi = rng.next(), u_theta = rng.next();
+        out = sampleDir(reflect(I, pn), TRT_RAY_SPECULAR, m.Ns, u_phi, u_theta);
+        return TRT_RAY_SPECULAR;
+    }
+    out = mk(0.f, 0.f, 0.f);
+    return TRT_RAY_INVALID;
+}
+
+// --------------------------------------------------------- path machinery ----
+struct Vertex {
+    V3 P, pn, wi, Kd;
+    const trt_material* m;
+};
+
+struct PathTracer {
+    const SceneView& sv;
+    Counters& cnt;
+    Tracer closest{sv, &cnt, 0};
+    Tracer shadow{sv, &cnt, 1};
+
+    PathTracer(const SceneView& v, Counters& c) : sv(v), cnt(c) {}
+
+    // hit point, shading normal, albedo: bvh.cpp:203,223-224, pathTracing.cpp:15-30
+    Vertex makeVertex(const Hit& h, V3 o, V3 d) const
+    {
+        const trt_scene* s = sv.s;
+        Vertex vx;
+        vx.P = mk(o.x + d.x * h.t, o.y + d.y * h.t, o.z + d.z * h.t);
+        vx.wi = -d;
+        const float b0 = (1.0f - h.u) - h.v, b1 = h.u, b2 = h.v;
+        const float* vn = s->tri_vn + (size_t)h.tri * 9;
+        vx.pn = normalize((ld(vn) * b0 + ld(vn + 3) * b1) + ld(vn + 6) * b2);
+        vx.m = &s->materials[s->tri_mat[h.tri]];
+        if (vx.m->tex >= 0) {
+            const trt_texture& tx = s->textures[vx.m->tex];
+            const float* vt = s->tri_vt + (size_t)h.tri * 6;
+            const float colf = (vt[0] * b0 + vt[2] * b1) + vt[4] * b2;  // float products and sums, widened on assignment
+            const float rowf = (vt[1] * b0 + vt[3] * b1) + vt[5] * b2;
+            const double col = colf, row = rowf;
+            const double irow = row - std::floor(row), icol = col - std::floor(col);
+            int r = (int)(irow * tx.height), c = (int)(icol * tx.width);
+            if (r > tx.height - 1) r = tx.height - 1;  // frac == 1.0 reads out of bounds in the reference
+            if (c > tx.width - 1) c = tx.width - 1;
+            if (r < 0) r = 0;
+            if (c < 0) c = 0;
+            const uint8_t* px = tx.rgb + ((size_t)r * tx.width + c) * 3;
+            vx.Kd = mk((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+        } else {
+            vx.Kd = ld(vx.m->Kd);
+        }
+        return vx;
+    }
+
+    // One light of the NEE loop (pathTracing.cpp:34-74).  Returns true and the
+    // unweighted contribution when the sample is visible and front-facing.
+    bool lightSample(const Vertex& vx, uint32_t li, Stream& rng, V3& contrib)
+    {
+        const trt_scene* s = sv.s;
+        const trt_light& L = s->lights[li];
+        // Q3: the CDF draw always spans the FIRST light's area (static u1, pathTracing.cpp:38)
+        const float rnd = rng.next() * s->lights[0].area;
+        const trt_light_tri* lt = nullptr;
+        for (uint32_t k = 0; k < L.tri_count; ++k)
+            if (rnd < s->light_tris[L.tri_first + k].cum_area) { lt = &s->light_tris[L.tri_first + k]; break; }
+        if (!lt) return false;
+        const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
+        const float rs = (r1 + r2) + r3;
+        const float p1 = r1 / rs, p2 = r2 / rs, p3 = r3 / rs;
+        const V3 light_p = (ld(lt->v[0]) * p1 + ld(lt->v[1]) * p2) + ld(lt->v[2]) * p3;
+        const V3 light_n = normalize((ld(lt->vn[0]) * p1 + ld(lt->vn[1]) * p2) + ld(lt->vn[2]) * p3);
+        const V3 diff = light_p - vx.P;
+        const V3 wo = normalize(diff);
+        const float cos_s = dot(wo, vx.pn);
+        if (!(cos_s > 0.0f)) return false;  // the reference traces and then discards (pathTracing.cpp:60)
+        cnt.rays[1]++;
+        const Hit h = shadow.closest(vx.P, wo);
+        // Q5: visible iff the CLOSEST hit carries the light's material (pathTracing.cpp:54-58)
+        if (h.tri < 0 || s->tri_mat[h.tri] != L.mat) return false;
+        const float pdf_light = 1.0f / L.area;
+        const float cos_theta_p = fabsf(dot(wo, light_n));
+        const float cos_theta = fabsf(cos_s / length(vx.pn));
+        const V3 radiance = ld(s->materials[L.mat].radiance);
+        const V3 intensity = (((radiance * cos_theta_p) * cos_theta) / dot(diff, diff)) / pdf_light;
+        const V3 hv = normalize((vx.wi + wo) * 0.5f);
+        const float ca = dot(vx.pn, hv);
+        const float cos_alpha = ca > 0.0f ? ca : 0.0f;
+        const float pw = trt_pow01(cos_alpha, vx.m->Ns);
+        const V3 spec = ((ld(vx.m->Ks) * (vx.m->Ns + 2.0f)) * pw) / (2.0f * TRT_PI);
+        const V3 brdf = vx.Kd / TRT_PI + spec;
+        contrib = intensity * brdf;
+        return true;
+    }
+
+    // ITERATIVE form of shade(): L += beta * L_dir per vertex; beta = (beta*w)/P_RR per bounce.
+    V3 pathIterative(V3 o, V3 d, Stream& rng, int max_depth, float* dbg = nullptr, int dbg_cap = 0, int* dbg_n = nullptr)
+    {
+        V3 L = mk(0, 0, 0), beta = mk(1, 1, 1);
+        int prev_type = -1;  // camera
+        cnt.rays[0]++;
+        for (uint32_t depth = 0;; ++depth) {
+            const Hit h = closest.closest(o, d);
+            int type_out = -2;
+            if (h.tri >= 0) {
+                if (depth > cnt.max_bounces) cnt.max_bounces = depth;
+                const trt_material& hm = sv.s->materials[sv.s->tri_mat[h.tri]];
+                if (hm.is_emissive) {
+                    // pathTracing.cpp:9-12 returns the radiance; the caller keeps it only for the
+                    // camera ray (main.cpp:101) and for TRANSMISSION (pathTracing.cpp:87-96, Q9)
+                    if (depth == 0) L = L + ld(hm.radiance);
+                    else if (prev_type == TRT_RAY_TRANSMISSION) L = L + beta * ld(hm.radiance);
+                } else {
+                    cnt.shaded++;
+                    const Vertex vx = makeVertex(h, o, d);
+                    for (uint32_t li = 0; li < sv.s->n_lights; ++li) {
+                        V3 c;
+                        if (lightSample(vx, li, rng, c)) L = L + beta * c;
+                    }
+                    const bool last = max_depth > 0 && (int)depth + 1 >= max_depth;
+                    if (!last && rng.next() < TRT_P_RR) {  // RR, pathTracing.cpp:78,104-109
+                        V3 nd;
+                        const int type = nextRay(*vx.m, vx.pn, d, rng, nd);
+                        type_out = type;
+                        if (type != TRT_RAY_INVALID) {
+                            const V3 w = (type == TRT_RAY_TRANSMISSION) ? ld(vx.m->Tr) : vx.Kd;  // Q8
+                            beta = (beta * w) / TRT_P_RR;
+                            o = vx.P;  // Q6: no offset
+                            d = nd;
+                            prev_type = type;
+                            cnt.rays[2]++;
+                            if (dbg && dbg_n && *dbg_n < dbg_cap) {
+                                float* r = dbg + (size_t)(*dbg_n) * 8;
+                                r[0] = h.t; r[1] = (float)h.tri; r[2] = h.u; r[3] = h.v; r[4] = L.x; r[5] = L.y; r[6] = L.z; r[7] = (float)type_out;
+                                (*dbg_n)++;
+                            }
+                            continue;
+                        }
+                    }
+                }
+            }
+            if (dbg && dbg_n && *dbg_n < dbg_cap) {
+                float* r = dbg + (size_t)(*dbg_n) * 8;
+                r[0] = h.t; r[1] = (float)h.tri; r[2] = h.u; r[3] = h.v; r[4] = L.x; r[5] = L.y; r[6] = L.z; r[7] = (float)type_out;
+                (*dbg_n)++;
+            }
+            return L;
+        }
+    }
+
+    // RECURSIVE form: shade() as written (pathTracing.cpp:3-102).
+    V3 shadeRecursive(const Hit& h, V3 o, V3 d, Stream& rng, uint32_t depth)
+    {
+        if (depth > cnt.max_bounces) cnt.max_bounces = depth;
+        const trt_material& hm = sv.s->materials[sv.s->tri_mat[h.tri]];
+        if (hm.is_emissive) return ld(hm.radiance);
+        cnt.shaded++;
+        V3 L_dir = mk(0, 0, 0), L_indir = mk(0, 0, 0);
+        const Vertex vx = makeVertex(h, o, d);
+        for (uint32_t li = 0; li < sv.s->n_lights; ++li) {
+            V3 c;
+            if (lightSample(vx, li, rng, c)) L_dir = L_dir + c;
+        }
+        if (rng.next() < TRT_P_RR) {
+            V3 nd;
+            const int type = nextRay(*vx.m, vx.pn, d, rng, nd);
+            if (type != TRT_RAY_INVALID) {  // the reference also traces INVALID rays and drops the result
+                cnt.rays[2]++;
+                const Hit ret = closest.closest(vx.P, nd);
+                if (ret.tri >= 0) {
+                    const V3 intensity = shadeRecursive(ret, vx.P, nd, rng, depth + 1) / TRT_P_RR;
+                    const bool ret_emissive = sv.emissive(ret.tri);
+                    if (type == TRT_RAY_TRANSMISSION) L_indir = L_indir + ld(vx.m->Tr) * intensity;
+                    else if (!ret_emissive) L_indir = L_indir + vx.Kd * intensity;
+                }
+            }
+        }
+        return L_dir + L_indir;
+    }
+
+    V3 pathRecursive(V3 o, V3 d, Stream& rng)
+    {
+        cnt.rays[0]++;
+        const Hit h = closest.closest(o, d);
+        if (h.tri < 0) return mk(0, 0, 0);
+        return shadeRecursive(h, o, d, rng, 0);
+    }
+};
+
+// main.cpp:88-95 + camera.cpp:19-28
+inline void cameraRay(const trt_camera& cam, int W, int H, int i, int j, float u1, float u2, V3& o, V3& d)
+{
+    double x = double(j) / double(W - 1.0);
+    double y = double(H - i) / double(H - 1.0);  // Q1: H - i
+    x += ((double)u1 - 0.5) / double(W);         // Q2
+    y += ((double)u2 - 0.5) / double(H);
+    const float s = (float)x, t = (float)y;
+    const V3 llc = ld(cam.lower_left_corner), hor = ld(cam.horizontal), ver = ld(cam.vertical), eye = ld(cam.eye);
+    o = eye;
+    d = normalize(((llc + hor * s) + ver * t) - eye);
+}
+
+int checkParams(const trt_scene* s, const trt_params* p)
+{
+    if (!s || !p) return TRT_EINVAL;
+    if (p->width < 2 || p->height < 2 || p->spp < 1) return TRT_EINVAL;
+    if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 >= p->x1 || p->y0 >= p->y1) return TRT_EINVAL;
+    if (s->n_nodes < 1 || !s->nodes) return TRT_EINVAL;
+    if (p->row_mod > 1 && (p->row_block < 1 || p->row_rem < 0 || p->row_rem >= p->row_mod)) return TRT_EINVAL;
+    return TRT_OK;
+}
+
+inline bool rowSelected(const trt_params* p, int y)
+{
+    if (p->row_mod <= 1) return true;
+    return ((y / p->row_block) % p->row_mod) == p->row_rem;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats, int threads, int mode)
+{
+    if (int e = checkParams(scene, p)) return e;
+    if (!out_rgb) return TRT_EINVAL;
+    const SceneView sv(scene);
+    std::vector<int> rows;
+    for (int y = p->y0; y < p->y1; ++y)
+        if (rowSelected(p, y)) rows.push_back(y);
+    const int tw = p->x1 - p->x0;
+    if (threads <= 0) threads = omp_get_num_procs();
+    Counters total;
+    const auto t_begin = std::chrono::steady_clock::now();
+#pragma omp parallel num_threads(threads)
+    {
+        Counters cnt;
+        PathTracer pt(sv, cnt);
+#pragma omp for schedule(dynamic, 1)
+        for (long r = 0; r < (long)rows.size(); ++r) {
+            const int i = rows[(size_t)r];
+            for (int j = p->x0; j < p->x1; ++j) {
+                double acc[3] = {0, 0, 0};  // `double* image`, main.cpp:74
+                const uint32_t pixel = (uint32_t)i * (uint32_t)p->width + (uint32_t)j;
+                for (int k = 0; k < p->spp; ++k) {  // the reference's OMP loop over k (main.cpp:81), here per pixel and race-free
+                    Stream rng{trt_rng_make_key(p->seed, pixel, (uint32_t)k), 0};
+                    const float u1 = rng.next(), u2 = rng.next();
+                    V3 o, d;
+                    cameraRay(scene->camera, p->width, p->height, i, j, u1, u2, o, d);
+                    const V3 L = (mode == ORACLE_MODE_RECURSIVE) ? pt.pathRecursive(o, d, rng) : pt.pathIterative(o, d, rng, p->max_depth);
+                    const V3 color = L / (float)p->spp;  // main.cpp:101
+                    acc[0] += color.x;
+                    acc[1] += color.y;
+                    acc[2] += color.z;
+                }
+                float* px = out_rgb + ((size_t)r * tw + (size_t)(j - p->x0)) * 3;
+                px[0] = (float)acc[0];
+                px[1] = (float)acc[1];
+                px[2] = (float)acc[2];
+            }
+        }
+#pragma omp critical
+        total.add(cnt);
+    }
+    const auto t_end = std::chrono::steady_clock::now();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays_camera = total.rays[0];
+        stats->rays_shadow = total.rays[1];
+        stats->rays_indirect = total.rays[2];
+        stats->shaded_hits = total.shaded;
+        for (int i = 0; i < 2; ++i) { stats->inner_visits[i] = total.inner[i]; stats->tri_tests[i] = total.tests[i]; }
+        stats->max_bounces = total.max_bounces;
+        stats->threads = threads;
+        stats->seconds = std::chrono::duration<double>(t_end - t_begin).count();
+    }
+    return TRT_OK;
+}
+
+int oracle_trace(const trt_scene* scene, uint64_t n, const float* org, const float* dir, float* t, int32_t* tri, float* uv, int mode, oracle_stats* stats)
+{
+    if (!scene || !org || !dir || !t || !tri || scene->n_nodes < 1) return TRT_EINVAL;
+    const SceneView sv(scene);
+    Counters total;
+#pragma omp parallel
+    {
+        Counters cnt;
+        Tracer tr{sv, &cnt, 0};
+#pragma omp for schedule(static)
+        for (long long i = 0; i < (long long)n; ++i) {
+            const V3 o = ld(org + i * 3), d = ld(dir + i * 3);
+            const Hit h = (mode == ORACLE_TRACE_BRUTE) ? tr.brute(o, d) : tr.closest(o, d);
+            t[i] = h.t;
+            tri[i] = h.tri;
+            if (uv) { uv[i * 2] = h.u; uv[i * 2 + 1] = h.v; }
+        }
+#pragma omp critical
+        total.add(cnt);
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->inner_visits[0] = total.inner[0];
+        stats->tri_tests[0] = total.tests[0];
+    }
+    return TRT_OK;
+}
+
+// buildBVH (bvh.cpp:16-144) restated on an index array.  Kept quirks: the node
+// box is padded by 0.001 (:31-40); both the per-axis `cost` and the overall
+// `Cost` start at INF = 114514 (:49,96), so whenever every candidate
+// SA_L*n_L + SA_R*n_R is >= 114514 (any scene measured in centimetres) no
+// candidate wins and the split falls back to Axis 0, Split = (l+r)/2.
+namespace {
+struct RefBuilder {
+    const float* v;
+    std::vector<uint32_t>& idx;
+    std::vector<trt_bvh_node>& nodes;
+    int leaf_num;
+    uint32_t max_depth = 0;
+
+    V3 vert(uint32_t tri, int k) const { return ld(v + (size_t)tri * 9 + k * 3); }
+    float centre(uint32_t tri, int axis) const
+    {
+        const V3 c = ((vert(tri, 0) + vert(tri, 1)) + vert(tri, 2)) / 3.0f;  // scene.cpp:197
+        return axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
+    }
+    void triBounds(uint32_t tri, V3& lo, V3& hi) const
+    {
+        const V3 a = vert(tri, 0), b = vert(tri, 1), c = vert(tri, 2);
+        lo = mk(gmin(a.x, gmin(b.x, c.x)), gmin(a.y, gmin(b.y, c.y)), gmin(a.z, gmin(b.z, c.z)));
+        hi = mk(gmax(a.x, gmax(b.x, c.x)), gmax(a.y, gmax(b.y, c.y)), gmax(a.z, gmax(b.z, c.z)));
+    }
+    void sortAxis(int l, int r, int axis)
+    {
+        std::stable_sort(idx.begin() + l, idx.begin() + r + 1, [&](uint32_t a, uint32_t b) { return centre(a, axis) < centre(b, axis); });
+    }
+    void nodeBox(int l, int r, float* lo3, float* hi3) const
+    {
+        V3 AA = mk(1145141919.f, 1145141919.f, 1145141919.f), BB = mk(-1145141919.f, -1145141919.f, -1145141919.f);
+        for (int i = l; i <= r; ++i) {
+            V3 lo, hi;
+            triBounds(idx[i], lo, hi);
+            AA = mk(gmin(AA.x, lo.x - 0.001f), gmin(AA.y, lo.y - 0.001f), gmin(AA.z, lo.z - 0.001f));
+            BB = mk(gmax(BB.x, hi.x + 0.001f), gmax(BB.y, hi.y + 0.001f), gmax(BB.z, hi.z + 0.001f));
+        }
+        lo3[0] = AA.x; lo3[1] = AA.y; lo3[2] = AA.z;
+        hi3[0] = BB.x; hi3[1] = BB.y; hi3[2] = BB.z;
+    }
+    uint32_t build(int l, int r, uint32_t depth)
+    {
+        const int n = r - l + 1;
+        if (n <= leaf_num) {
+            max_depth = std::max(max_depth, depth);
+            return TRT_MAKE_LEAF(l, n);
+        }
+        float Cost = TRT_INF;
+        int Axis = 0, Split = (l + r) / 2;
+        std::vector<V3> lmax(n), lmin(n), rmax(n), rmin(n);
+        for (int axis = 0; axis < 3; ++axis) {
+            sortAxis(l, r, axis);
+            for (int i = l; i <= r; ++i) {
+                V3 lo, hi;
+                triBounds(idx[i], lo, hi);
+                const int k = i - l;
+                if (k == 0) { lmax[k] = mk(gmax(-TRT_INF, hi.x), gmax(-TRT_INF, hi.y), gmax(-TRT_INF, hi.z)); lmin[k] = mk(gmin(TRT_INF, lo.x), gmin(TRT_INF, lo.y), gmin(TRT_INF, lo.z)); }
+                else { lmax[k] = mk(gmax(lmax[k - 1].x, hi.x), gmax(lmax[k - 1].y, hi.y), gmax(lmax[k - 1].z, hi.z)); lmin[k] = mk(gmin(lmin[k - 1].x, lo.x), gmin(lmin[k - 1].y, lo.y), gmin(lmin[k - 1].z, lo.z)); }
+            }
+            for (int i = r; i >= l; --i) {
+                V3 lo, hi;
+                triBounds(idx[i], lo, hi);
+                const int k = i - l;
+                if (i == r) { rmax[k] = mk(gmax(-TRT_INF, hi.x), gmax(-TRT_INF, hi.y), gmax(-TRT_INF, hi.z)); rmin[k] = mk(gmin(TRT_INF, lo.x), gmin(TRT_INF, lo.y), gmin(TRT_INF, lo.z)); }
+                else { rmax[k] = mk(gmax(rmax[k + 1].x, hi.x), gmax(rmax[k + 1].y, hi.y), gmax(rmax[k + 1].z, hi.z)); rmin[k] = mk(gmin(rmin[k + 1].x, lo.x), gmin(rmin[k + 1].y, lo.y), gmin(rmin[k + 1].z, lo.z)); }
+            }
+            float cost = TRT_INF;
+            int split = l;
+            for (int i = l; i <= r - 1; ++i) {
+                const V3 la = lmin[i - l], lb = lmax[i - l];
+                float xl = lb.x - la.x, yl = lb.y - la.y, zl = lb.z - la.z;
+                const float lsa = (float)(2.0 * ((xl * yl) + (xl * zl) + (yl * zl)));
+                const float lcost = lsa * (float)(i - l + 1);
+                const V3 ra = rmin[i + 1 - l], rb = rmax[i + 1 - l];
+                xl = rb.x - ra.x; yl = rb.y - ra.y; zl = rb.z - ra.z;
+                const float rsa = (float)(2.0 * ((xl * yl) + (xl * zl) + (yl * zl)));
+                const float rcost = rsa * (float)(r - i);
+                const float total = lcost + rcost;
+                if (total < cost) { cost = total; split = i; }
+            }
+            if (cost < Cost) { Cost = cost; Axis = axis; Split = split; }
+        }
+        sortAxis(l, r, Axis);
+        const uint32_t me = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        const uint32_t c0 = build(l, Split, depth + 1);
+        const uint32_t c1 = build(Split + 1, r, depth + 1);
+        trt_bvh_node& nd = nodes[me];
+        std::memset(&nd, 0, sizeof(nd));
+        // the children's boxes are computed after the subtree builds: their triangle sets are final by then
+        nodeBox(l, Split, nd.lo0, nd.hi0);
+        nodeBox(Split + 1, r, nd.lo1, nd.hi1);
+        nd.child0 = c0;
+        nd.child1 = c1;
+        return me;
+    }
+};
+}  // namespace
+
+int oracle_build_bvh(uint32_t n, const float* tri_v, int leaf_num, uint32_t* perm, trt_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* depth)
+{
+    if (!tri_v || !perm || !nodes_out || !n_nodes || leaf_num < 1 || leaf_num > (int)TRT_MAX_LEAF_TRIS) return TRT_EINVAL;
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+    std::vector<trt_bvh_node> nodes;
+    RefBuilder b{tri_v, idx, nodes, leaf_num};
+    if ((int)n <= leaf_num) {
+        trt_bvh_node root;
+        std::memset(&root, 0, sizeof(root));
+        if (n) b.nodeBox(0, (int)n - 1, root.lo0, root.hi0);
+        std::memcpy(root.lo1, root.lo0, sizeof(root.lo0));
+        std::memcpy(root.hi1, root.hi0, sizeof(root.hi0));
+        root.child0 = TRT_MAKE_LEAF(0, n);
+        root.child1 = TRT_MAKE_LEAF(0, 0);
+        nodes.push_back(root);
+        b.max_depth = 1;
+    } else {
+        b.build(0, (int)n - 1, 0);
+    }
+    for (uint32_t i = 0; i < n; ++i) perm[i] = idx[i];
+    std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(trt_bvh_node));
+    *n_nodes = (uint32_t)nodes.size();
+    if (depth) *depth = b.max_depth;
+    return TRT_OK;
+}
+
+int oracle_tri_test(const float v[9], const float o[3], const float d[3], float out[3])
+{
+    Tri t;
+    t.v0 = ld(v);
+    t.e1 = ld(v + 3) - t.v0;
+    t.e2 = ld(v + 6) - t.v0;
+    const V3 g = cross(t.e1, t.e2);
+    t.tol = TRT_PARALLEL_EPS * sqrtf(dot(g, g));
+    float tt, u, vv;
+    if (!triTest(t, ld(o), ld(d), tt, u, vv)) return 0;
+    out[0] = tt; out[1] = u; out[2] = vv;
+    return 1;
+}
+
+float oracle_aabb(const float lo[3], const float hi[3], const float o[3], const float d[3])
+{
+    const V3 dd = ld(d);
+    return aabb(lo, hi, ld(o), mk(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z));
+}
+
+void oracle_sample(const float axis[3], int ray_type, float Ns, float u_phi, float u_theta, float out[3])
+{
+    const V3 r = sampleDir(ld(axis), ray_type, Ns, u_phi, u_theta);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+void oracle_reflect(const float I[3], const float N[3], float out[3])
+{
+    const V3 r = reflect(ld(I), ld(N));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+void oracle_refract(const float I[3], const float N[3], float eta, float out[3])
+{
+    const V3 r = refract(ld(I), ld(N), eta);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+void oracle_camera_ray(const trt_camera* cam, int width, int height, int i, int j, float u1, float u2, float org[3], float dir[3])
+{
+    V3 o, d;
+    cameraRay(*cam, width, height, i, j, u1, u2, o, d);
+    org[0] = o.x; org[1] = o.y; org[2] = o.z;
+    dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+}
+
+int oracle_next_ray(const trt_material* m, const float pn[3], const float incoming[3], uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t* ctr, float out_dir[3])
+{
+    Stream rng{trt_rng_make_key(seed, pixel, sample), *ctr};
+    V3 out;
+    const int type = nextRay(*m, ld(pn), ld(incoming), rng, out);
+    *ctr = rng.ctr;
+    out_dir[0] = out.x; out_dir[1] = out.y; out_dir[2] = out.z;
+    return type;
+}
+
+void oracle_prims_sincos2pi(float u, float* c, float* s) { trt_sincos2pi(u, c, s); }
+float oracle_prims_pow01(float x, float y) { return trt_pow01(x, y); }
+float oracle_prims_uniform(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t i) { return trt_rng_uniform(trt_rng_make_key(seed, pixel, sample), i); }
+
+int oracle_debug_path(const trt_scene* scene, const trt_params* p, int x, int y, int sample, float* out, int max_vertices)
+{
+    if (checkParams(scene, p) || !out) return -1;
+    const SceneView sv(scene);
+    Counters cnt;
+    PathTracer pt(sv, cnt);
+    const uint32_t pixel = (uint32_t)y * (uint32_t)p->width + (uint32_t)x;
+    Stream rng{trt_rng_make_key(p->seed, pixel, (uint32_t)sample), 0};
+    const float u1 = rng.next(), u2 = rng.next();
+    V3 o, d;
+    cameraRay(scene->camera, p->width, p->height, y, x, u1, u2, o, d);
+    int n = 0;
+    pt.pathIterative(o, d, rng, p->max_depth, out, max_vertices, &n);
+    return n;
+}
+
+}  // extern "C"

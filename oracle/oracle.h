@@ -1,0 +1,76 @@
+/*
+ * oracle.h — C interface of the CPU oracle (oracle/liboracle.so).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under tinyraytracing_amd/ may include,
+ * link or call this; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do.  See oracle.cpp for what it restates and how it is
+ * (not) pinned.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include "trt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_stats {
+    uint64_t rays_camera, rays_shadow, rays_indirect, shaded_hits;
+    uint64_t inner_visits[2]; /* [closest, shadow] */
+    uint64_t tri_tests[2];
+    uint32_t max_bounces;
+    int32_t threads;
+    double seconds;           /* wall time of the render loop only */
+} oracle_stats;
+
+#define ORACLE_MODE_ITERATIVE 0 /* beta-weighted loop: the bit-parity target of the HIP path */
+#define ORACLE_MODE_RECURSIVE 1 /* literal recursion of shade() (pathTracing.cpp:3-102) */
+
+/* main.cpp:80-113 restated.  Same trt_params semantics as trt_render (tile,
+ * row interleave, packed float output).  threads <= 0 -> all cores. */
+int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats,
+                  int threads, int mode);
+
+#define ORACLE_TRACE_REFERENCE 0 /* recursive, both children, no culling (bvh.cpp:146-175) */
+#define ORACLE_TRACE_BRUTE 1     /* every triangle in index order through the leaf rule */
+int oracle_trace(const trt_scene* scene, uint64_t n, const float* org, const float* dir,
+                 float* t, int32_t* tri, float* uv, int mode, oracle_stats* stats);
+
+/* buildBVH (bvh.cpp:16-144) restated, including its Cost = INF start value.
+ * perm[i] = input index of the triangle that ends up at position i;
+ * nodes must hold 2*n entries. */
+int oracle_build_bvh(uint32_t n, const float* tri_v, int leaf_num, uint32_t* perm,
+                     trt_bvh_node* nodes, uint32_t* n_nodes, uint32_t* depth);
+
+/* ---- known-answer entry points for unit tests -------------------------------- */
+/* interactTriangle (bvh.cpp:177-209): returns 1 on hit, out = {t, u, v}. */
+int oracle_tri_test(const float v[9], const float o[3], const float d[3], float out[3]);
+/* interactAABB (bvh.cpp:231-245). */
+float oracle_aabb(const float lo[3], const float hi[3], const float o[3], const float d[3]);
+/* Sample (pathTracing.cpp:111-145) with explicit uniforms (phi draw first). */
+void oracle_sample(const float axis[3], int ray_type, float Ns, float u_phi, float u_theta, float out[3]);
+void oracle_reflect(const float I[3], const float N[3], float out[3]);
+void oracle_refract(const float I[3], const float N[3], float eta, float out[3]);
+/* main.cpp:88-95 + camera.cpp:19-28 for pixel row i, column j with jitter draws u1,u2. */
+void oracle_camera_ray(const trt_camera* cam, int width, int height, int i, int j, float u1, float u2,
+                       float org[3], float dir[3]);
+/* nextRay (pathTracing.cpp:147-209) on explicit inputs; draws come from (seed,pixel,sample) at
+ * counter *ctr (advanced).  Returns the ray type; out_dir is the new direction. */
+int oracle_next_ray(const trt_material* m, const float pn[3], const float incoming[3], uint32_t seed,
+                    uint32_t pixel, uint32_t sample, uint32_t* ctr, float out_dir[3]);
+/* the shared primitives, exported so tests can check them against libm */
+void oracle_prims_sincos2pi(float u, float* c, float* s);
+float oracle_prims_pow01(float x, float y);
+float oracle_prims_uniform(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t i);
+
+/* One path, vertex by vertex, for debugging parity failures: for each path
+ * vertex writes 8 floats {t, tri, u, v, L.r, L.g, L.b, ray_type_out}. Returns the
+ * number of vertices written (<= max_vertices). */
+int oracle_debug_path(const trt_scene* scene, const trt_params* p, int x, int y, int sample,
+                      float* out, int max_vertices);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,236 @@
+"""tinyraytracing_amd — MI355X-native path-tracing hot path of TinyRayTracing.
+
+Python is the thin host layer used by tests and bench.py; the compute path is
+libtrt_hip.so (hand-written HIP for gfx950, include/trt.h) and the loaders are
+libtrt_host.so (C++, include/trt_host.h).  The classes mirror the reference's
+driver (main.cpp:44-119): load the scene (readxml -> readobj -> readmtl), build
+the BVH, render(), imshow().
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import Params, Stats, SceneFlat, TRT_FLAG_COUNT, TRT_FLAG_TIMING, KERNEL_NAMES  # noqa: F401
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES_DIR = os.path.join(REPO_ROOT, "scenes")
+
+# seeds fixed by SURVEY.md §8d / BASELINE.md §2
+SEED_BACK = 0x5EED0001
+SEED_SOUP = 0x5EED0003
+SEED_STAIRCASE = 0x5EED0004
+SEED_BLOB = 0x5EED0005
+
+_BUILDERS = {"sweep": 0, "binned": 1, "auto": 2}
+
+
+class TrtError(RuntimeError):
+    pass
+
+
+class Scene:
+    """Scene + BVH + flat arrays (reference: Scene in scene.h:19-36 and buildBVH, bvh.cpp:16)."""
+
+    def __init__(self, handle):
+        self._lib = _abi.load_host()
+        self._h = handle
+        self._built = False
+
+    @classmethod
+    def load(cls, xml_path, obj_path, mtl_path, basedir, width=0, height=0):
+        """scene.readxml(xml); scene.readobj(obj); scene.readmtl(mtl, basedir) (main.cpp:66-69).
+        width/height override the XML resolution."""
+        lib = _abi.load_host()
+        h = lib.trth_scene_load(os.fsencode(xml_path), os.fsencode(obj_path), os.fsencode(mtl_path),
+                                os.fsencode(basedir), int(width), int(height))
+        if not h:
+            raise TrtError(lib.trth_last_error().decode())
+        return cls(h)
+
+    @classmethod
+    def named(cls, name, width=0, height=0, leaf_num=8, builder="auto", n=None, seed=None):
+        """Shipped and synthetic scenes: back, veach-mis, staircase, soup (n random triangles in
+        the back box, BASELINE config 3), blob (displaced geodesic sphere, config 5)."""
+        if name in ("back", "veach-mis", "staircase"):
+            d = os.path.join(SCENES_DIR, name)
+            s = cls.load(os.path.join(d, name + ".xml"), os.path.join(d, name + ".obj"), os.path.join(d, name + ".mtl"), d, width, height)
+        elif name in ("soup", "blob"):
+            d = os.path.join(SCENES_DIR, "back")
+            s = cls.load(os.path.join(d, "back.xml"), os.path.join(d, "back.obj"), os.path.join(d, "back.mtl"), d, width, height)
+            s._check(s._lib.trth_scene_drop_tris(s._h, 6, 12))  # the cube of back.obj (faces 7..18)
+            if name == "soup":
+                s._check(s._lib.trth_scene_add_soup(s._h, SEED_SOUP if seed is None else seed, 1_000_000 if n is None else int(n)))
+            else:
+                s._check(s._lib.trth_scene_add_blob(s._h, SEED_BLOB if seed is None else seed, 10_000_000 if n is None else int(n)))
+        else:
+            raise TrtError(f"unknown scene {name!r}")
+        s.build_bvh(leaf_num, builder)
+        return s
+
+    def _check(self, rc):
+        if rc != 0:
+            raise TrtError(self._lib.trth_last_error().decode())
+
+    def build_bvh(self, leaf_num=8, builder="auto"):
+        """BVHNode* root = buildBVH(scene.triangles, 0, n-1, 8) (main.cpp:76) + flattening."""
+        self._check(self._lib.trth_scene_build(self._h, int(leaf_num), _BUILDERS[builder]))
+        self._built = True
+        return self
+
+    @property
+    def flat(self):
+        p = self._lib.trth_scene_flat(self._h)
+        if not p:
+            raise TrtError(self._lib.trth_last_error().decode())
+        return p
+
+    @property
+    def info(self):
+        arr = (C.c_int64 * 8)()
+        self._check(self._lib.trth_scene_info(self._h, arr))
+        keys = ["width", "height", "n_vertices", "n_vn", "n_vt", "n_triangles", "n_materials", "n_lights"]
+        return dict(zip(keys, [int(x) for x in arr]))
+
+    def light_area(self, i):
+        return float(self._lib.trth_scene_light_area(self._h, i))
+
+    def material_name(self, i):
+        s = self._lib.trth_scene_material_name(self._h, i)
+        if s is None:
+            raise TrtError(self._lib.trth_last_error().decode())
+        return s.decode()
+
+    # numpy views of the flat arrays (copies), mostly for tests
+    def arrays(self):
+        f = self.flat.contents
+        n = f.n_tris
+        out = {
+            "tri_v": np.ctypeslib.as_array(f.tri_v, shape=(n, 3, 3)).copy() if n else np.zeros((0, 3, 3), np.float32),
+            "tri_vn": np.ctypeslib.as_array(f.tri_vn, shape=(n, 3, 3)).copy() if n else np.zeros((0, 3, 3), np.float32),
+            "tri_vt": np.ctypeslib.as_array(f.tri_vt, shape=(n, 3, 2)).copy() if n else np.zeros((0, 3, 2), np.float32),
+            "tri_mat": np.ctypeslib.as_array(f.tri_mat, shape=(n,)).copy() if n else np.zeros((0,), np.int32),
+            "n_nodes": int(f.n_nodes),
+            "bvh_depth": int(f.bvh_depth),
+        }
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.trth_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_params(width, height, spp, seed, tile=None, rows=None, max_depth=0, flags=0, mem_budget=0):
+    p = Params()
+    p.width, p.height, p.spp, p.seed = int(width), int(height), int(spp), int(seed) & 0xFFFFFFFF
+    x0, y0, x1, y1 = tile if tile is not None else (0, 0, width, height)
+    p.x0, p.y0, p.x1, p.y1 = int(x0), int(y0), int(x1), int(y1)
+    rb, rm, rr = rows if rows is not None else (1, 1, 0)
+    p.row_block, p.row_mod, p.row_rem = int(rb), int(rm), int(rr)
+    p.max_depth, p.flags, p.mem_budget = int(max_depth), int(flags), int(mem_budget)
+    return p
+
+
+def rows_selected(p):
+    """Image rows a Params selects, in output order (mirrors trt_rows_selected)."""
+    ys = range(p.y0, p.y1)
+    if p.row_mod <= 1:
+        return list(ys)
+    return [y for y in ys if (y // p.row_block) % p.row_mod == p.row_rem]
+
+
+class Renderer:
+    """Owns a trt_handle: the scene resident in HBM of one MI355X."""
+
+    def __init__(self, scene, device=0):
+        self._lib = _abi.load_hip()  # raises if the HIP extension is missing
+        self._scene = scene          # keep the flat arrays alive
+        h = C.c_void_p()
+        rc = self._lib.trt_create(scene.flat, int(device), C.byref(h))
+        if rc != 0:
+            raise TrtError(f"trt_create failed ({rc}): {self._lib.trt_last_error().decode()}")
+        self._h = h
+        self.device = int(device)
+
+    def render(self, params):
+        """render() -> (float32 image [rows, tile_w, 3] linear radiance, Stats).  Host output."""
+        nrows = self._lib.trt_rows_selected(C.byref(params))
+        tw = params.x1 - params.x0
+        if nrows <= 0 or tw <= 0:
+            raise TrtError("render: empty tile")
+        out = np.empty((nrows, tw, 3), dtype=np.float32)
+        st = Stats()
+        rc = self._lib.trt_render(self._h, C.byref(params), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
+        if rc != 0:
+            raise TrtError(f"trt_render failed ({rc}): {self._lib.trt_last_error().decode()}")
+        return out, st
+
+    def render_into(self, params, out_tensor, stream_ptr=0):
+        """Renders into a CUDA/HIP torch tensor (float32, >= rows*tile_w*3 elements) on this device."""
+        nrows = self._lib.trt_rows_selected(C.byref(params))
+        tw = params.x1 - params.x0
+        need = nrows * tw * 3
+        if out_tensor.numel() < need or str(out_tensor.dtype) != "torch.float32" or not out_tensor.is_cuda or not out_tensor.is_contiguous():
+            raise TrtError("render_into: need a contiguous float32 device tensor with rows*tile_w*3 elements")
+        st = Stats()
+        rc = self._lib.trt_render_device(self._h, C.byref(params), C.c_void_p(out_tensor.data_ptr()), C.c_void_p(stream_ptr), C.byref(st))
+        if rc != 0:
+            raise TrtError(f"trt_render_device failed ({rc}): {self._lib.trt_last_error().decode()}")
+        return st
+
+    def trace_closest(self, org, direction, want_stats=False):
+        """traverseBVH on a ray batch: returns (t, tri, uv[, Stats])."""
+        org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        direction = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+        n = org.shape[0]
+        if direction.shape[0] != n:
+            raise TrtError("trace_closest: org/dir length mismatch")
+        t = np.empty(n, np.float32)
+        tri = np.empty(n, np.int32)
+        uv = np.empty((n, 2), np.float32)
+        st = Stats()
+        fp = C.POINTER(C.c_float)
+        rc = self._lib.trt_trace_closest(self._h, n, org.ctypes.data_as(fp), direction.ctypes.data_as(fp), t.ctypes.data_as(fp),
+                                         tri.ctypes.data_as(C.POINTER(C.c_int32)), uv.ctypes.data_as(fp), C.byref(st))
+        if rc != 0:
+            raise TrtError(f"trt_trace_closest failed ({rc}): {self._lib.trt_last_error().decode()}")
+        return (t, tri, uv, st) if want_stats else (t, tri, uv)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.trt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tonemap(image):
+    """imshow()'s transfer: (uchar) clamp(pow(x, 1/2.2f) * 255, 0, 255) (main.cpp:34-36)."""
+    lib = _abi.load_host()
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    h, w = img.shape[0], img.shape[1]
+    out = np.empty((h, w, 3), np.uint8)
+    if lib.trth_tonemap(img.ctypes.data_as(C.POINTER(C.c_float)), w, h, out.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
+        raise TrtError(lib.trth_last_error().decode())
+    return out
+
+
+def imshow(image, path):
+    """Writes the linear image as <path> (PNG, stored deflate) after the reference's gamma."""
+    lib = _abi.load_host()
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    h, w = img.shape[0], img.shape[1]
+    if lib.trth_write_png(os.fsencode(path), w, h, img.ctypes.data_as(C.POINTER(C.c_float))) != 0:
+        raise TrtError(lib.trth_last_error().decode())
