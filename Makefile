@@ -20,14 +20,18 @@ HOST_HDR := $(wildcard $(PKG)/host/*.h) include/trt.h include/trt_host.h include
 HIP_SRC := $(PKG)/csrc/trt_api.hip
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h
 
-.PHONY: all host hip oracle cli clean
-all: host hip oracle cli
+.PHONY: all host hip oracle cli hostsim clean
+all: host hip oracle hostsim cli
 
 host: $(OUT)/libtrt_host.so
 hip: $(OUT)/libtrt_hip.so
 cli: $(OUT)/tinyrt
 oracle:
 	$(MAKE) -C oracle
+# CPU compile of the device-side path functions, for tests only (tests/hostsim)
+hostsim: tests/hostsim/libhostsim.so
+tests/hostsim/libhostsim.so: tests/hostsim/hostsim.cpp $(HIP_HDR)
+	$(CXX) $(CXXFLAGS) -fopenmp -I$(PKG)/csrc -shared -o $@ tests/hostsim/hostsim.cpp
 
 $(OUT)/libtrt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(OUT)
@@ -41,5 +45,5 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h 
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -Wl,-rpath,'$$ORIGIN'
 
 clean:
-	rm -rf $(OUT)
+	rm -rf $(OUT) tests/hostsim/libhostsim.so
 	$(MAKE) -C oracle clean

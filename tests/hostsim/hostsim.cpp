@@ -1,0 +1,160 @@
+// hostsim.cpp — TEST INFRASTRUCTURE.  Compiles the device-side path functions
+// (tinyraytracing_amd/csrc/trt_path.h: traversal, triangle/box tests,
+// shadeBegin / lightSample / shadeNext) with g++ and drives them per path in
+// the wavefront kernels' order of operations, so their arithmetic can be checked
+// bit-for-bit against the oracle on a machine without a GPU.  It is not a render
+// back end: nothing in the product loads this library.
+#include <cstring>
+#include <vector>
+
+#include "trt_path.h"
+
+using namespace trtd;
+
+namespace {
+struct ArrayStack {
+    uint32_t s[320];
+    void push(int sp, uint32_t v) { s[sp] = v; }
+    uint32_t pop(int sp) const { return s[sp]; }
+};
+
+struct HostScene {
+    std::vector<TriIsect> isect;
+    std::vector<TriShade> shade;
+    std::vector<MaterialDev> mats;
+    std::vector<TextureDev> tex;
+    std::vector<uint8_t> tex_bytes;
+    SceneDev sc{};
+    explicit HostScene(const trt_scene* s)
+    {
+        isect.resize(s->n_tris);
+        shade.resize(s->n_tris);
+        for (uint32_t i = 0; i < s->n_tris; ++i) {
+            const int32_t mat = s->tri_mat[i];
+            isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, mat, s->materials[mat].is_emissive != 0);
+            std::memcpy(shade[i].vn, s->tri_vn + (size_t)i * 9, 36);
+            std::memcpy(shade[i].vt, s->tri_vt + (size_t)i * 6, 24);
+            shade[i].mat = mat;
+        }
+        mats.resize(s->n_materials);
+        for (uint32_t i = 0; i < s->n_materials; ++i) {
+            const trt_material& m = s->materials[i];
+            MaterialDev& d = mats[i];
+            std::memcpy(d.Kd, m.Kd, 12); std::memcpy(d.Ks, m.Ks, 12); std::memcpy(d.Tr, m.Tr, 12);
+            d.Ns = m.Ns; d.Ni = m.Ni;
+            std::memcpy(d.radiance, m.radiance, 12);
+            d.is_emissive = m.is_emissive; d.tex = m.tex;
+        }
+        tex.resize(s->n_textures);
+        for (uint32_t i = 0; i < s->n_textures; ++i) {
+            tex[i].width = s->textures[i].width;
+            tex[i].height = s->textures[i].height;
+            tex[i].offset = tex_bytes.size();
+            const size_t nb = (size_t)tex[i].width * tex[i].height * 3;
+            tex_bytes.insert(tex_bytes.end(), s->textures[i].rgb, s->textures[i].rgb + nb);
+        }
+        sc.nodes = s->nodes;
+        sc.tri_isect = isect.data();
+        sc.tri_shade = shade.data();
+        sc.materials = mats.data();
+        sc.lights = s->lights;
+        sc.light_tris = s->light_tris;
+        sc.textures = tex.data();
+        sc.tex_bytes = tex_bytes.data();
+        sc.n_tris = s->n_tris;
+        sc.n_nodes = s->n_nodes;
+        sc.n_lights = s->n_lights;
+        sc.light0_area = s->n_lights ? s->lights[0].area : 0.0f;
+        sc.cam = s->camera;
+    }
+};
+}  // namespace
+
+extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* out_rgb, uint64_t rays[3])
+{
+    if (!s || !p || !out_rgb) return 1;
+    HostScene hs(s);
+    std::vector<int32_t> rows;
+    for (int y = p->y0; y < p->y1; ++y)
+        if (p->row_mod <= 1 || ((y / p->row_block) % p->row_mod) == p->row_rem) rows.push_back(y);
+    const uint32_t tw = (uint32_t)(p->x1 - p->x0), npix = (uint32_t)rows.size() * tw;
+    TileDesc td;
+    td.rows = rows.data();
+    td.tile_w = (int32_t)tw; td.x0 = p->x0; td.width = p->width; td.height = p->height;
+    td.npix = npix; td.seed = p->seed; td.spp = (uint32_t)p->spp;
+    uint64_t r_cam = 0, r_sh = 0, r_ind = 0;
+    const uint32_t S = (uint32_t)p->spp;  // one chunk: path id = s * npix + pixel
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : r_cam, r_sh, r_ind)
+    for (long pl = 0; pl < (long)npix; ++pl) {
+        ArrayStack stk;
+        uint32_t ni = 0, nt = 0;
+        double acc[3] = {0, 0, 0};
+        for (uint32_t sidx = 0; sidx < S; ++sidx) {
+            const uint32_t pid = sidx * npix + (uint32_t)pl;
+            // k_gen_primary
+            const uint32_t r = (uint32_t)pl / tw, c = (uint32_t)pl - r * tw;
+            const int y = rows[r], x = p->x0 + (int)c;
+            Stream rng;
+            rng.key = trt_rng_make_key(td.seed, (uint32_t)y * (uint32_t)td.width + (uint32_t)x, sidx);
+            rng.ctr = 0;
+            const float u1 = rng.next(), u2 = rng.next();
+            f3 o, d;
+            cameraRay(hs.sc.cam, td.width, td.height, y, x, u1, u2, o, d);
+            f4 ra = mk4(o.x, o.y, o.z, d.x), rb = mk4(d.y, d.z, u2f(pid), u2f(packMeta(rng.ctr, TRT_META_CAMERA, 0))), bt = mk4(1, 1, 1, 0);
+            f3 L = mk3(0, 0, 0);
+            r_cam++;
+            for (;;) {
+                // k_trace_closest
+                const Hit h = traceClosest<ArrayStack, false>(hs.sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni, nt);
+                const f4 hit4 = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
+                // k_shade
+                ShadeCtx cx;
+                shadeBegin(hs.sc, td, 0, ra, rb, bt, hit4, cx);
+                if (cx.add_L) L = L + cx.addL;
+                for (uint32_t li = 0; li < hs.sc.n_lights; ++li) {
+                    f3 wo, contrib;
+                    if (!cx.shade_ok || !lightSample(hs.sc, cx.vx, cx.m, li, cx.rng, wo, contrib)) continue;
+                    const f3 w = cx.beta * contrib;
+                    r_sh++;
+                    // k_trace_shadow
+                    const Hit sh = traceClosest<ArrayStack, false>(hs.sc, cx.vx.P, wo, stk, ni, nt);
+                    if (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)hs.sc.lights[li].mat) L = L + w;
+                }
+                f4 nra, nrb, nbt;
+                if (!shadeNext(cx, p->max_depth, nra, nrb, nbt)) break;
+                ra = nra; rb = nrb; bt = nbt;
+                r_ind++;
+            }
+            // k_resolve
+            const float spp = (float)p->spp;
+            acc[0] += (double)(L.x / spp);
+            acc[1] += (double)(L.y / spp);
+            acc[2] += (double)(L.z / spp);
+        }
+        out_rgb[(size_t)pl * 3 + 0] = (float)acc[0];
+        out_rgb[(size_t)pl * 3 + 1] = (float)acc[1];
+        out_rgb[(size_t)pl * 3 + 2] = (float)acc[2];
+    }
+    if (rays) { rays[0] = r_cam; rays[1] = r_sh; rays[2] = r_ind; }
+    return 0;
+}
+
+extern "C" int hostsim_trace(const trt_scene* s, uint64_t n, const float* org, const float* dir, float* t, int32_t* tri, float* uv, uint64_t counts[2])
+{
+    if (!s || !org || !dir || !t || !tri) return 1;
+    HostScene hs(s);
+    uint64_t ci = 0, ct = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ci, ct)
+    for (long long i = 0; i < (long long)n; ++i) {
+        ArrayStack stk;
+        uint32_t ni = 0, nt = 0;
+        const Hit h = traceClosest<ArrayStack, true>(hs.sc, ld3(org + i * 3), ld3(dir + i * 3), stk, ni, nt);
+        t[i] = h.t;
+        tri[i] = h.tri;
+        if (uv) { uv[i * 2] = h.u; uv[i * 2 + 1] = h.v; }
+        ci += ni;
+        ct += nt;
+    }
+    if (counts) { counts[0] = ci; counts[1] = ct; }
+    return 0;
+}

@@ -1,0 +1,538 @@
+// trt_api.hip — C-ABI implementation (include/trt.h) for gfx950: scene upload,
+// the wavefront render loop that replaces main.cpp:79-113, and the ray-batch
+// traversal entry.  No CPU compute path exists in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "trt.h"
+#include "trt_kernels.h"
+
+using namespace trtd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPC(expr)                                                                                         \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? TRT_ENOMEM : TRT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr uint32_t MAX_TRACE_BLOCKS = 8192;                       // persistent grid cap of the traversal kernels
+constexpr uint32_t SPILL_STRIDE = MAX_TRACE_BLOCKS * TRT_TRACE_BLOCK;
+constexpr uint32_t MAX_BOUNCES = TRT_MAX_PATH_DEPTH + 2;
+constexpr uint32_t COUNT_ROW = 16;                                // u32 per bounce: [0] = queue length, [1+l] = shadow rays of light l
+constexpr uint32_t MAX_BVH_DEPTH = 256;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return TRT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        HIPC(hipMalloc(&p, need));
+        bytes = need;
+        return TRT_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct trt_handle {
+    int device = 0;
+    SceneDev sc{};
+    std::vector<void*> scene_allocs;
+    std::vector<uint32_t> light_mats;
+    uint32_t depth = 0;
+    DevBuf arena, spill, small_buf, out_buf, io_buf;
+    std::vector<hipEvent_t> events;
+    ~trt_handle()
+    {
+        for (void* p : scene_allocs) (void)hipFree(p);
+        arena.release();
+        spill.release();
+        small_buf.release();
+        out_buf.release();
+        io_buf.release();
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+template <class T>
+int upload(trt_handle* h, const T* src, size_t count, const T** dst)
+{
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIPC(hipMalloc(&p, bytes));
+    h->scene_allocs.push_back(p);
+    if (count) HIPC(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T*)p;
+    return TRT_OK;
+}
+
+// Structural check of the flat BVH and its true depth (the kernels size their
+// stacks from it): every child reference in range, every leaf range in range,
+// no node reachable twice (no cycles / DAGs).
+int validateBvh(const trt_scene* s, uint32_t* depth_out)
+{
+    std::vector<uint8_t> seen(s->n_nodes, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> stack;  // (node, depth of this inner node, 1-based)
+    stack.emplace_back(0u, 1u);
+    uint32_t max_depth = 0;
+    std::vector<uint8_t> tri_seen(s->n_tris, 0);
+    while (!stack.empty()) {
+        const auto [ni, dep] = stack.back();
+        stack.pop_back();
+        if (ni >= s->n_nodes) return fail(TRT_EINVAL, "bvh: child index out of range");
+        if (seen[ni]) return fail(TRT_EINVAL, "bvh: node reachable twice");
+        seen[ni] = 1;
+        if (dep > MAX_BVH_DEPTH) return fail(TRT_EINVAL, "bvh: deeper than 256 levels");
+        max_depth = std::max(max_depth, dep);
+        const uint32_t ch[2] = {s->nodes[ni].child0, s->nodes[ni].child1};
+        for (uint32_t c : ch) {
+            if (c & TRT_LEAF_BIT) {
+                const uint32_t first = TRT_LEAF_FIRST(c), count = TRT_LEAF_COUNT(c);
+                if ((uint64_t)first + count > s->n_tris) return fail(TRT_EINVAL, "bvh: leaf range out of bounds");
+                for (uint32_t i = first; i < first + count; ++i) {
+                    if (tri_seen[i]) return fail(TRT_EINVAL, "bvh: triangle in two leaves");
+                    tri_seen[i] = 1;
+                }
+            } else {
+                stack.emplace_back(c, dep + 1);
+            }
+        }
+    }
+    *depth_out = max_depth;
+    return TRT_OK;
+}
+
+int checkParams(const trt_handle* h, const trt_params* p)
+{
+    if (!h || !p) return fail(TRT_EINVAL, "null handle/params");
+    if (p->width < 2 || p->height < 2) return fail(TRT_EINVAL, "width and height must be >= 2 (x = j/(W-1), main.cpp:88)");
+    if (p->spp < 1) return fail(TRT_EINVAL, "spp must be >= 1");
+    if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 >= p->x1 || p->y0 >= p->y1) return fail(TRT_EINVAL, "tile rectangle outside the image or empty");
+    if (p->row_mod > 1 && (p->row_block < 1 || p->row_rem < 0 || p->row_rem >= p->row_mod)) return fail(TRT_EINVAL, "bad row interleave");
+    if (p->max_depth < 0) return fail(TRT_EINVAL, "max_depth must be >= 0");
+    if ((uint64_t)p->width * (uint64_t)p->height > 0xFFFFFFFFull) return fail(TRT_EINVAL, "image too large");
+    return TRT_OK;
+}
+
+bool rowSelected(const trt_params* p, int y) { return p->row_mod <= 1 || ((y / p->row_block) % p->row_mod) == p->row_rem; }
+
+uint32_t traceGrid(uint32_t n)
+{
+    uint32_t b = (n + TRT_TRACE_BLOCK - 1) / TRT_TRACE_BLOCK;
+    b = std::min(std::max(b, 8u), MAX_TRACE_BLOCKS);
+    return (b + 7u) & ~7u;  // multiple of 8 for the XCD swizzle; <= MAX_TRACE_BLOCKS since that is one too
+}
+
+struct Timer {
+    trt_handle* h;
+    hipStream_t stream;
+    bool on;
+    size_t used = 0;
+    struct Span { int k; size_t e0, e1; };
+    std::vector<Span> spans;
+    hipEvent_t get(size_t i)
+    {
+        while (h->events.size() <= i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            h->events.push_back(e);
+        }
+        return h->events[i];
+    }
+    // events 0/1 bracket the whole render; per-kernel spans only with TRT_FLAG_TIMING
+    void begin(int k)
+    {
+        if (!on) return;
+        hipEvent_t e = get(2 + used);
+        if (e) (void)hipEventRecord(e, stream);
+        spans.push_back({k, 2 + used, 0});
+        used++;
+    }
+    void end()
+    {
+        if (!on) return;
+        hipEvent_t e = get(2 + used);
+        if (e) (void)hipEventRecord(e, stream);
+        spans.back().e1 = 2 + used;
+        used++;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* trt_last_error(void) { return g_err.c_str(); }
+int trt_abi_version(void) { return TRT_ABI_VERSION; }
+
+int trt_rows_selected(const trt_params* p)
+{
+    if (!p) return -1;
+    int n = 0;
+    for (int y = p->y0; y < p->y1; ++y) n += rowSelected(p, y) ? 1 : 0;
+    return n;
+}
+
+int trt_create(const trt_scene* s, int device, trt_handle** out)
+{
+    if (!s || !out) return fail(TRT_EINVAL, "trt_create: null argument");
+    *out = nullptr;
+    if (s->n_nodes < 1 || !s->nodes) return fail(TRT_EINVAL, "scene needs at least the root node");
+    if (s->n_tris > TRT_MAX_TRIS) return fail(TRT_EINVAL, "too many triangles");
+    if (s->n_tris && (!s->tri_v || !s->tri_vn || !s->tri_vt || !s->tri_mat)) return fail(TRT_EINVAL, "null triangle arrays");
+    if (s->n_lights > (uint32_t)TRT_MAX_LIGHTS) return fail(TRT_EINVAL, "more than 8 lights");
+    if (s->n_materials < 1 || !s->materials) return fail(TRT_EINVAL, "scene needs materials");
+    if (s->n_materials >= (1u << 24)) return fail(TRT_EINVAL, "too many materials");
+    for (uint32_t i = 0; i < s->n_tris; ++i)
+        if (s->tri_mat[i] < 0 || (uint32_t)s->tri_mat[i] >= s->n_materials) return fail(TRT_EINVAL, "triangle material id out of range");
+    for (uint32_t i = 0; i < s->n_materials; ++i)
+        if (s->materials[i].tex >= (int32_t)s->n_textures) return fail(TRT_EINVAL, "material texture id out of range");
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        const trt_light& L = s->lights[i];
+        if (L.mat < 0 || (uint32_t)L.mat >= s->n_materials) return fail(TRT_EINVAL, "light material id out of range");
+        if ((uint64_t)L.tri_first + L.tri_count > s->n_light_tris) return fail(TRT_EINVAL, "light triangle range out of bounds");
+    }
+    for (uint32_t i = 0; i < s->n_textures; ++i)
+        if (s->textures[i].width < 1 || s->textures[i].height < 1 || !s->textures[i].rgb) return fail(TRT_EINVAL, "empty texture");
+    uint32_t depth = 0;
+    if (int e = validateBvh(s, &depth)) return e;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(TRT_ENODEV, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(TRT_ENODEV, "device ordinal out of range");
+    HIPC(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(TRT_ENODEV, std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName);
+
+    std::unique_ptr<trt_handle> h(new trt_handle);
+    h->device = device;
+    h->depth = depth;
+
+    {   // 48-B intersection records and 64-B shading records
+        std::vector<TriIsect> isect(s->n_tris);
+        std::vector<TriShade> shade(s->n_tris);
+        for (uint32_t i = 0; i < s->n_tris; ++i) {
+            const int32_t mat = s->tri_mat[i];
+            isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, mat, s->materials[mat].is_emissive != 0);
+            std::memcpy(shade[i].vn, s->tri_vn + (size_t)i * 9, sizeof(float) * 9);
+            std::memcpy(shade[i].vt, s->tri_vt + (size_t)i * 6, sizeof(float) * 6);
+            shade[i].mat = mat;
+        }
+        if (int e = upload(h.get(), isect.data(), isect.size(), &h->sc.tri_isect)) return e;
+        if (int e = upload(h.get(), shade.data(), shade.size(), &h->sc.tri_shade)) return e;
+    }
+    if (int e = upload(h.get(), s->nodes, (size_t)s->n_nodes, &h->sc.nodes)) return e;
+    {
+        std::vector<MaterialDev> mats(s->n_materials);
+        for (uint32_t i = 0; i < s->n_materials; ++i) {
+            const trt_material& m = s->materials[i];
+            MaterialDev& d = mats[i];
+            std::memcpy(d.Kd, m.Kd, 12); std::memcpy(d.Ks, m.Ks, 12); std::memcpy(d.Tr, m.Tr, 12);
+            d.Ns = m.Ns; d.Ni = m.Ni;
+            std::memcpy(d.radiance, m.radiance, 12);
+            d.is_emissive = m.is_emissive; d.tex = m.tex;
+        }
+        if (int e = upload(h.get(), mats.data(), mats.size(), &h->sc.materials)) return e;
+    }
+    if (int e = upload(h.get(), s->lights, (size_t)s->n_lights, &h->sc.lights)) return e;
+    if (int e = upload(h.get(), s->light_tris, (size_t)s->n_light_tris, &h->sc.light_tris)) return e;
+    {
+        std::vector<TextureDev> tex(s->n_textures);
+        std::vector<uint8_t> bytes;
+        for (uint32_t i = 0; i < s->n_textures; ++i) {
+            tex[i].width = s->textures[i].width;
+            tex[i].height = s->textures[i].height;
+            tex[i].offset = bytes.size();
+            const size_t nb = (size_t)tex[i].width * tex[i].height * 3;
+            bytes.insert(bytes.end(), s->textures[i].rgb, s->textures[i].rgb + nb);
+        }
+        if (int e = upload(h.get(), tex.data(), tex.size(), &h->sc.textures)) return e;
+        if (int e = upload(h.get(), bytes.data(), bytes.size(), &h->sc.tex_bytes)) return e;
+    }
+    h->sc.n_tris = s->n_tris;
+    h->sc.n_nodes = s->n_nodes;
+    h->sc.n_lights = s->n_lights;
+    h->sc.light0_area = s->n_lights ? s->lights[0].area : 0.0f;
+    h->sc.cam = s->camera;
+    for (uint32_t i = 0; i < s->n_lights; ++i) h->light_mats.push_back((uint32_t)s->lights[i].mat);
+
+    // traversal spill area: levels beyond the LDS stack, for the largest grid
+    const uint32_t spill_levels = depth > (uint32_t)TRT_LDS_STACK ? depth - TRT_LDS_STACK + 1 : 1;
+    if (int e = h->spill.ensure((size_t)spill_levels * SPILL_STRIDE * sizeof(uint32_t))) return e;
+    *out = h.release();
+    return TRT_OK;
+}
+
+void trt_destroy(trt_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    delete h;
+}
+
+int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* hip_stream, trt_stats* stats_out)
+{
+    if (int e = checkParams(h, p)) return e;
+    if (!out_dev) return fail(TRT_EINVAL, "null output buffer");
+    HIPC(hipSetDevice(h->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool count = (p->flags & TRT_FLAG_COUNT) != 0;
+    const uint32_t nl = h->sc.n_lights;
+
+    std::vector<int32_t> rows;
+    for (int y = p->y0; y < p->y1; ++y)
+        if (rowSelected(p, y)) rows.push_back(y);
+    if (rows.empty()) return fail(TRT_EINVAL, "row interleave selects no rows of the tile");
+    const uint32_t tw = (uint32_t)(p->x1 - p->x0);
+    const uint64_t npix64 = (uint64_t)rows.size() * tw;
+    if (npix64 > 0x7FFFFFFFull) return fail(TRT_EINVAL, "tile too large");
+    const uint32_t npix = (uint32_t)npix64;
+
+    // ---- chunking: how many samples of every pixel are in flight at once ----
+    const uint64_t bytes_per_path = 2ull * 48 + 16 + 16 + (uint64_t)nl * 48;
+    uint64_t budget = p->mem_budget;
+    if (!budget) {
+        size_t free_b = 0, total_b = 0;
+        HIPC(hipMemGetInfo(&free_b, &total_b));
+        budget = std::min<uint64_t>((uint64_t)(free_b + h->arena.bytes) / 2, 32ull << 30);
+    }
+    uint64_t max_paths = std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull);
+    if (max_paths < npix) return fail(TRT_ENOMEM, "mem_budget too small for one sample of every pixel of the tile; render smaller tiles");
+    uint32_t s_chunk = (uint32_t)std::min<uint64_t>((uint64_t)p->spp, max_paths / npix);
+    const uint32_t n_chunks = ((uint32_t)p->spp + s_chunk - 1) / s_chunk;
+    s_chunk = ((uint32_t)p->spp + n_chunks - 1) / n_chunks;
+    const uint64_t N = (uint64_t)npix * s_chunk;
+
+    // ---- carve the arena -------------------------------------------------------
+    const size_t q16 = (size_t)N * sizeof(f4);
+    if (int e = h->arena.ensure(q16 * (3 * 2 + 1 + 1 + 3 * (size_t)nl))) return e;
+    f4* base = (f4*)h->arena.p;
+    auto take = [&]() { f4* r = base; base += N; return r; };
+    RayQueue Q[2];
+    for (int k = 0; k < 2; ++k) { Q[k].ra = take(); Q[k].rb = take(); Q[k].bt = take(); }
+    f4* hit = take();
+    f4* Lacc = take();
+    ShadowQueue SQ[TRT_MAX_LIGHTS] = {};
+    for (uint32_t l = 0; l < nl; ++l) { SQ[l].sa = take(); SQ[l].sb = take(); SQ[l].sw = take(); }
+
+    // small buffers: rows | counts | device stats | double accumulator
+    const size_t rows_bytes = (rows.size() * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t counts_bytes = (size_t)(MAX_BOUNCES + 2) * COUNT_ROW * sizeof(uint32_t);
+    const size_t stats_bytes = 256;
+    const size_t acc_bytes = (size_t)npix * 3 * sizeof(double);
+    if (int e = h->small_buf.ensure(rows_bytes + counts_bytes + stats_bytes + acc_bytes)) return e;
+    char* sb = (char*)h->small_buf.p;
+    int32_t* d_rows = (int32_t*)sb;
+    uint32_t* d_counts = (uint32_t*)(sb + rows_bytes);
+    DeviceStats* d_stats = (DeviceStats*)(sb + rows_bytes + counts_bytes);
+    double* d_acc = (double*)(sb + rows_bytes + counts_bytes + stats_bytes);
+    HIPC(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIPC(hipMemsetAsync(d_stats, 0, sizeof(DeviceStats), stream));
+    HIPC(hipMemsetAsync(d_acc, 0, acc_bytes, stream));
+
+    TileDesc td;
+    td.rows = d_rows;
+    td.tile_w = (int32_t)tw;
+    td.x0 = p->x0;
+    td.width = p->width;
+    td.height = p->height;
+    td.npix = npix;
+    td.seed = p->seed;
+    td.spp = (uint32_t)p->spp;
+
+    Timer tm{h, stream, (p->flags & TRT_FLAG_TIMING) != 0};
+    trt_stats st;
+    std::memset(&st, 0, sizeof(st));
+    hipEvent_t ev_begin = tm.get(0), ev_end = tm.get(1);
+    if (!ev_begin || !ev_end) return fail(TRT_EHIP, "hipEventCreate failed");
+    HIPC(hipEventRecord(ev_begin, stream));
+
+    uint32_t* spill = (uint32_t*)h->spill.p;
+    std::vector<uint32_t> host_counts(2 * COUNT_ROW);
+    uint32_t deepest = 0;
+    for (uint32_t chunk = 0; chunk < n_chunks; ++chunk) {
+        const uint32_t s0 = chunk * s_chunk;
+        const uint32_t sc_count = std::min(s_chunk, (uint32_t)p->spp - s0);
+        const uint32_t n0 = npix * sc_count;
+        HIPC(hipMemsetAsync(d_counts, 0, counts_bytes, stream));
+        tm.begin(TRT_K_GEN_PRIMARY);
+        hipLaunchKernelGGL(k_gen_primary, dim3(std::min<uint32_t>((n0 + 255) / 256, 65536u)), dim3(256), 0, stream, h->sc, td, Q[0], Lacc, s0, n0);
+        tm.end();
+        st.launches[TRT_K_GEN_PRIMARY]++;
+        st.rays_camera += n0;
+
+        uint32_t n_active = n0;
+        int cur = 0;
+        for (uint32_t b = 0; n_active > 0 && b < MAX_BOUNCES; ++b) {
+            tm.begin(TRT_K_TRACE_CLOSEST);
+            if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(traceGrid(n_active)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, Q[cur].ra, Q[cur].rb, hit, n_active, spill, SPILL_STRIDE, d_stats);
+            else hipLaunchKernelGGL(k_trace_closest<false>, dim3(traceGrid(n_active)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, Q[cur].ra, Q[cur].rb, hit, n_active, spill, SPILL_STRIDE, d_stats);
+            tm.end();
+            st.launches[TRT_K_TRACE_CLOSEST]++;
+
+            ShadeArgs A;
+            A.qin = Q[cur];
+            A.hit = hit;
+            A.n = n_active;
+            A.qout = Q[cur ^ 1];
+            for (int l = 0; l < TRT_MAX_LIGHTS; ++l) A.sq[l] = SQ[l];
+            A.next_count = d_counts + (size_t)(b + 1) * COUNT_ROW;
+            A.shadow_counts = d_counts + (size_t)b * COUNT_ROW + 1;
+            A.Lacc = Lacc;
+            A.td = td;
+            A.s0 = s0;
+            A.max_depth = p->max_depth;
+            A.stats = d_stats;
+            tm.begin(TRT_K_SHADE);
+            hipLaunchKernelGGL(k_shade, dim3(std::min<uint32_t>((n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u)), dim3(TRT_SHADE_BLOCK), 0, stream, h->sc, A);
+            tm.end();
+            st.launches[TRT_K_SHADE]++;
+
+            // queue lengths of this bounce's shadow rays and of the next bounce
+            HIPC(hipMemcpyAsync(host_counts.data(), d_counts + (size_t)b * COUNT_ROW, 2 * COUNT_ROW * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIPC(hipStreamSynchronize(stream));
+            for (uint32_t l = 0; l < nl; ++l) {
+                const uint32_t ns = host_counts[1 + l];
+                if (ns > n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");
+                if (!ns) continue;
+                tm.begin(TRT_K_TRACE_SHADOW);
+                if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(traceGrid(ns)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, SQ[l], ns, h->light_mats[l], Lacc, spill, SPILL_STRIDE, d_stats);
+                else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(traceGrid(ns)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, SQ[l], ns, h->light_mats[l], Lacc, spill, SPILL_STRIDE, d_stats);
+                tm.end();
+                st.launches[TRT_K_TRACE_SHADOW]++;
+                st.rays_shadow += ns;
+            }
+            const uint32_t n_next = host_counts[COUNT_ROW];
+            if (n_next > n_active) return fail(TRT_EHIP, "internal error: queue grew");
+            st.rays_indirect += n_next;
+            n_active = n_next;
+            cur ^= 1;
+            deepest = std::max(deepest, b);
+        }
+        tm.begin(TRT_K_RESOLVE);
+        hipLaunchKernelGGL(k_resolve, dim3(std::min<uint32_t>((npix + 255) / 256, 65536u)), dim3(256), 0, stream, Lacc, d_acc, npix, sc_count, (float)p->spp);
+        tm.end();
+        st.launches[TRT_K_RESOLVE]++;
+    }
+    tm.begin(TRT_K_RESOLVE);
+    hipLaunchKernelGGL(k_finalize, dim3(std::min<uint32_t>((npix * 3 + 255) / 256, 65536u)), dim3(256), 0, stream, d_acc, out_dev, npix * 3);
+    tm.end();
+    HIPC(hipEventRecord(ev_end, stream));
+    DeviceStats ds;
+    HIPC(hipMemcpyAsync(&ds, d_stats, sizeof(ds), hipMemcpyDeviceToHost, stream));
+    HIPC(hipStreamSynchronize(stream));
+    HIPC(hipGetLastError());
+
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, ev_begin, ev_end));
+    st.render_ms = ms;
+    for (const auto& sp : tm.spans) {
+        float k_ms = 0.f;
+        if (hipEventElapsedTime(&k_ms, h->events[sp.e0], h->events[sp.e1]) == hipSuccess) st.kernel_ms[sp.k] += k_ms;
+    }
+    st.shaded_hits = ds.shaded_hits;
+    for (int i = 0; i < 2; ++i) { st.inner_visits[i] = ds.inner_visits[i]; st.tri_tests[i] = ds.tri_tests[i]; }
+    st.max_bounces = ds.max_depth_hit;
+    st.passes = n_chunks;
+    st.rows_rendered = rows.size();
+    (void)deepest;
+    if (stats_out) *stats_out = st;
+    return TRT_OK;
+}
+
+int trt_render(trt_handle* h, const trt_params* p, float* out_host, trt_stats* stats)
+{
+    if (int e = checkParams(h, p)) return e;
+    if (!out_host) return fail(TRT_EINVAL, "null output buffer");
+    HIPC(hipSetDevice(h->device));
+    const int nrows = trt_rows_selected(p);
+    if (nrows < 1) return fail(TRT_EINVAL, "row interleave selects no rows of the tile");
+    const size_t bytes = (size_t)nrows * (size_t)(p->x1 - p->x0) * 3 * sizeof(float);
+    if (int e = h->out_buf.ensure(bytes)) return e;
+    if (int e = trt_render_device(h, p, (float*)h->out_buf.p, nullptr, stats)) return e;
+    HIPC(hipMemcpy(out_host, h->out_buf.p, bytes, hipMemcpyDeviceToHost));
+    return TRT_OK;
+}
+
+int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* dir, float* t, int32_t* tri, float* uv, trt_stats* stats_out)
+{
+    if (!h || !org || !dir || !t || !tri) return fail(TRT_EINVAL, "trt_trace_closest: null argument");
+    if (n == 0) return TRT_OK;
+    if (n > 0x7FFF0000ull) return fail(TRT_EINVAL, "ray batch too large");
+    HIPC(hipSetDevice(h->device));
+    const uint32_t n32 = (uint32_t)n;
+    const size_t in_bytes = (size_t)n * 3 * sizeof(float);
+    const size_t q16 = (size_t)n * sizeof(f4);
+    if (int e = h->io_buf.ensure(2 * in_bytes + 3 * q16 + 256)) return e;
+    char* b = (char*)h->io_buf.p;
+    f4* ra = (f4*)b;
+    f4* rb = ra + n;
+    f4* hit = rb + n;
+    float* d_org = (float*)(hit + n);
+    float* d_dir = d_org + (size_t)n * 3;
+    DeviceStats* d_stats = (DeviceStats*)(d_dir + (size_t)n * 3);
+    d_stats = (DeviceStats*)(((uintptr_t)d_stats + 15) & ~(uintptr_t)15);
+    HIPC(hipMemcpy(d_org, org, in_bytes, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_dir, dir, in_bytes, hipMemcpyHostToDevice));
+    HIPC(hipMemset(d_stats, 0, sizeof(DeviceStats)));
+    hipLaunchKernelGGL(k_pack_rays, dim3(std::min<uint32_t>((n32 + 255) / 256, 65536u)), dim3(256), 0, nullptr, d_org, d_dir, ra, rb, n32);
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(traceGrid(n32)), dim3(TRT_TRACE_BLOCK), 0, nullptr, h->sc, ra, rb, hit, n32, (uint32_t*)h->spill.p, SPILL_STRIDE, d_stats);
+    HIPC(hipEventRecord(e1, nullptr));
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipGetLastError());
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::vector<f4> hh(n);
+    HIPC(hipMemcpy(hh.data(), hit, q16, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        t[i] = hh[i].x;
+        tri[i] = (int32_t)f2u(hh[i].y);
+        if (uv) { uv[i * 2] = hh[i].z; uv[i * 2 + 1] = hh[i].w; }
+    }
+    if (stats_out) {
+        DeviceStats ds;
+        HIPC(hipMemcpy(&ds, d_stats, sizeof(ds), hipMemcpyDeviceToHost));
+        std::memset(stats_out, 0, sizeof(*stats_out));
+        stats_out->inner_visits[0] = ds.inner_visits[0];
+        stats_out->tri_tests[0] = ds.tri_tests[0];
+        stats_out->kernel_ms[TRT_K_TRACE_CLOSEST] = ms;
+        stats_out->launches[TRT_K_TRACE_CLOSEST] = 1;
+    }
+    return TRT_OK;
+}
+
+}  // extern "C"

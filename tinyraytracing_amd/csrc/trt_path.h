@@ -1,0 +1,490 @@
+// trt_path.h — per-lane device functions of the path-tracing hot path:
+// BVH traversal, ray/triangle and ray/box tests, path-vertex set-up, light
+// sampling (NEE), Russian roulette and BSDF sampling.  The wavefront kernels
+// in trt_kernels.h are thin drivers around these.
+//
+// Every function is `TRT_HD` and free of device-only intrinsics, so the same
+// source also compiles with g++ for tests/hostsim (a CPU check of this file's
+// arithmetic against the oracle; test infrastructure, not a product path).
+//
+// Arithmetic contract (include/trt_prims.h, DESIGN.md "Formulation"): fp32,
+// compiled with -ffp-contract=off, FMA only where written.  Reference
+// citations are file:line under RayTracingOnCPU/.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#include "trt.h"
+#include "trt_prims.h"
+
+namespace trtd {
+
+// ------------------------------------------------------------------ types ----
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+struct f3 {
+    float x, y, z;
+};
+
+TRT_HD inline f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+TRT_HD inline f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+TRT_HD inline f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+TRT_HD inline f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+TRT_HD inline f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+TRT_HD inline f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+TRT_HD inline f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+TRT_HD inline f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+TRT_HD inline f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+// glm evaluation order: dot = (x + y) + z; normalize = v * (1 / sqrt(dot(v, v)))
+TRT_HD inline float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+TRT_HD inline f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+TRT_HD inline float length(f3 a) { return sqrtf(dot(a, a)); }
+TRT_HD inline f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+// glm::reflect / glm::refract (pathTracing.cpp:177,184,202)
+TRT_HD inline f3 reflect(f3 I, f3 N) { return I - (N * dot(N, I)) * 2.0f; }
+TRT_HD inline f3 refract(f3 I, f3 N, float eta)
+{
+    const float dn = dot(N, I);
+    const float k = 1.0f - eta * eta * (1.0f - dn * dn);
+    if (k < 0.0f) return mk3(0.f, 0.f, 0.f);
+    return I * eta - N * (eta * dn + sqrtf(k));
+}
+
+TRT_HD inline uint32_t f2u(float f) { return trt_f2u(f); }
+TRT_HD inline float u2f(uint32_t u) { return trt_u2f(u); }
+
+// ------------------------------------------------------- device scene view ----
+// 48-B intersection record per triangle (post-BVH order), three 16-B loads:
+//   a = (v0.x, v0.y, v0.z, e1.x)  b = (e1.y, e1.z, e2.x, e2.y)
+//   c = (e2.z, tol, bits(flags), 0)     tol = 1e-5 * |e1 x e2|
+//   flags: bit 0 = material is emissive (Triangle::is_emissive), bits 8.. = material id
+struct TriIsect {
+    f4 a, b, c;
+};
+// 64-B shading record: vertex normals, texture coordinates, material id
+struct alignas(16) TriShade {
+    float vn[9];
+    float vt[6];
+    int32_t mat;
+};
+struct MaterialDev {
+    float Kd[3], Ks[3], Tr[3];
+    float Ns, Ni;
+    float radiance[3];
+    int32_t is_emissive;
+    int32_t tex;  // -1 = none
+};
+struct TextureDev {
+    int32_t width, height;
+    uint64_t offset;  // into tex_bytes
+};
+
+struct SceneDev {
+    const trt_bvh_node* nodes;
+    const TriIsect* tri_isect;
+    const TriShade* tri_shade;
+    const MaterialDev* materials;
+    const trt_light* lights;
+    const trt_light_tri* light_tris;
+    const TextureDev* textures;
+    const uint8_t* tex_bytes;
+    uint32_t n_tris, n_nodes, n_lights;
+    float light0_area;  // Q3: every light's CDF draw spans lights[0].area (pathTracing.cpp:38)
+    trt_camera cam;
+};
+
+struct Hit {
+    float t;         // TRT_INF on a miss (HitRecord::distance default, bvh.h:10)
+    int32_t tri;     // -1 on a miss
+    float u, v;      // barycentric weights of v1, v2
+    uint32_t flags;  // TriIsect flags of the hit triangle: bit 0 emissive, bits 8.. material id
+};
+
+// Build-time helper shared by trt_create and the hostsim: the 48-B record of one triangle.
+TRT_HD inline TriIsect makeTriIsect(const float* v9, int32_t mat, bool emissive)
+{
+    const f3 v0 = ld3(v9), e1 = ld3(v9 + 3) - v0, e2 = ld3(v9 + 6) - v0;
+    const f3 g = cross(e1, e2);
+    const float tol = TRT_PARALLEL_EPS * sqrtf(dot(g, g));
+    TriIsect r;
+    r.a = mk4(v0.x, v0.y, v0.z, e1.x);
+    r.b = mk4(e1.y, e1.z, e2.x, e2.y);
+    r.c = mk4(e2.z, tol, u2f(((uint32_t)mat << 8) | (emissive ? 1u : 0u)), 0.0f);
+    return r;
+}
+
+// ------------------------------------------------ interactTriangle (a6) ----
+// bvh.cpp:177-209 in Moller-Trumbore form: the parallel cut
+// |N.d| < 1e-5 is |det| < tol, t < 0.0005 misses, and "strictly inside"
+// (bvh.cpp:196-198) is u > 0, v > 0, u + v < 1.  The divisions are deferred
+// until the sign tests have passed.
+TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& u_out, float& v_out)
+{
+    const float v0x = T.a.x, v0y = T.a.y, v0z = T.a.z;
+    const float e1x = T.a.w, e1y = T.b.x, e1z = T.b.y;
+    const float e2x = T.b.z, e2y = T.b.w, e2z = T.c.x;
+    const float px = fmaf(d.y, e2z, -(d.z * e2y));
+    const float py = fmaf(d.z, e2x, -(d.x * e2z));
+    const float pz = fmaf(d.x, e2y, -(d.y * e2x));
+    float det = fmaf(e1z, pz, fmaf(e1y, py, e1x * px));
+    if (fabsf(det) < T.c.y) return false;  // bvh.cpp:185
+    const float tx = o.x - v0x, ty = o.y - v0y, tz = o.z - v0z;
+    float un = fmaf(tz, pz, fmaf(ty, py, tx * px));
+    const float qx = fmaf(ty, e1z, -(tz * e1y));
+    const float qy = fmaf(tz, e1x, -(tx * e1z));
+    const float qz = fmaf(tx, e1y, -(ty * e1x));
+    float vn = fmaf(d.z, qz, fmaf(d.y, qy, d.x * qx));
+    float tn = fmaf(e2z, qz, fmaf(e2y, qy, e2x * qx));
+    if (det < 0.0f) { det = -det; un = -un; vn = -vn; tn = -tn; }
+    if (!(un > 0.0f && vn > 0.0f && (un + vn) < det)) return false;  // strict: edge points miss
+    const float t = tn / det;
+    if (t < TRT_T_MIN) return false;  // bvh.cpp:189
+    t_out = t;
+    u_out = un / det;
+    v_out = vn / det;
+    return true;
+}
+
+// ---------------------------------------------------- interactAABB (a4) ----
+// bvh.cpp:231-245: slab test; `entry` receives t0 (used for ordering/culling).
+// fminf/fmaxf differ from glm's ternaries only for NaN operands (an axis with
+// d == 0 and the origin exactly on the padded plane).
+TRT_HD inline bool boxTest(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float& entry)
+{
+    const float inx = (hix - o.x) * inv.x, iny = (hiy - o.y) * inv.y, inz = (hiz - o.z) * inv.z;
+    const float outx = (lox - o.x) * inv.x, outy = (loy - o.y) * inv.y, outz = (loz - o.z) * inv.z;
+    const float t1 = fminf(fmaxf(inx, outx), fminf(fmaxf(iny, outy), fmaxf(inz, outz)));
+    const float t0 = fmaxf(fminf(inx, outx), fmaxf(fminf(iny, outy), fminf(inz, outz)));
+    entry = t0;
+    const float r = (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+    return r > 0.0f;  // the caller descends iff the result is > 0 (bvh.cpp:162-166)
+}
+
+// ------------------------------------------------------ traverseBVH (a3) ----
+// Closest hit with the reference's result semantics (bvh.cpp:146-175,
+// 211-229) on an explicit stack: children are visited nearest-first and a
+// subtree is skipped only when its box entry is STRICTLY beyond the best hit,
+// so every equal-distance candidate is still seen.  Tie rules (Q10):
+//   inside a leaf   — index order; replace when nearer, or equal and emissive
+//                     (bvh.cpp:219);
+//   between leaves  — the reference's sibling merge "r1 if r1 emissive else r2"
+//                     (bvh.cpp:168-172), with r1 the lower-index subtree, is
+//                     order independent as: leftmost emissive wins, otherwise the
+//                     rightmost candidate wins.
+// Stack: push(sp, ref) / pop(sp) with sp < scene depth.
+template <class Stack, bool COUNT>
+TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri)
+{
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    Hit best;
+    best.t = TRT_INF; best.tri = -1; best.u = 0.f; best.v = 0.f; best.flags = 0u;
+    int sp = 0;
+    uint32_t cur = 0;  // nodes[0] is always an inner node
+    for (;;) {
+        if (cur & TRT_LEAF_BIT) {
+            const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
+            float lt = TRT_INF, lu = 0.f, lv = 0.f;
+            int32_t li = -1;
+            uint32_t lflags = 0u;
+            for (uint32_t i = first; i < first + count; ++i) {
+                const TriIsect T = sc.tri_isect[i];
+                if (COUNT) n_tri++;
+                float t, u, v;
+                if (!triTest(T, o, d, t, u, v)) continue;
+                const uint32_t fl = f2u(T.c.z);
+                if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lu = u; lv = v; lflags = fl; }
+            }
+            if (li >= 0) {
+                bool take = lt < best.t;
+                if (lt == best.t && best.tri >= 0) {
+                    const bool lem = (lflags & 1u) != 0, bem = (best.flags & 1u) != 0;
+                    take = lem ? (!bem || li < best.tri) : (!bem && li > best.tri);
+                }
+                if (take) { best.t = lt; best.tri = li; best.u = lu; best.v = lv; best.flags = lflags; }
+            }
+            if (sp == 0) break;
+            cur = stk.pop(--sp);
+            continue;
+        }
+        // one 64-B node = four 16-B loads: (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (child0, child1, -, -)
+        const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + cur);
+        const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
+        if (COUNT) n_inner++;
+        float e0, e1;
+        bool h0 = boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
+        bool h1 = boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
+        const uint32_t child0 = f2u(q3.x), child1 = f2u(q3.y);
+        h0 = h0 && !(e0 > best.t);
+        h1 = h1 && !(e1 > best.t);
+        if (h0 && h1) {
+            const bool swap = e1 < e0;
+            stk.push(sp++, swap ? child0 : child1);
+            cur = swap ? child1 : child0;
+        } else if (h0) {
+            cur = child0;
+        } else if (h1) {
+            cur = child1;
+        } else {
+            if (sp == 0) break;
+            cur = stk.pop(--sp);
+        }
+    }
+    return best;
+}
+
+// --------------------------------------------------------------- RNG stream ----
+struct Stream {
+    trt_rng_key key;
+    uint32_t ctr;
+    TRT_HD float next() { return trt_rng_uniform(key, ctr++); }
+};
+
+// ------------------------------------- primary ray (main.cpp:88-95, a1/a2) ----
+TRT_HD inline void cameraRay(const trt_camera& cam, int W, int H, int i, int j, float u1, float u2, f3& o, f3& d)
+{
+    double x = double(j) / double(W - 1.0);
+    double y = double(H - i) / double(H - 1.0);  // Q1
+    x += ((double)u1 - 0.5) / double(W);         // Q2
+    y += ((double)u2 - 0.5) / double(H);
+    const float s = (float)x, t = (float)y;
+    const f3 llc = ld3(cam.lower_left_corner), hor = ld3(cam.horizontal), ver = ld3(cam.vertical), eye = ld3(cam.eye);
+    o = eye;
+    d = normalize(((llc + hor * s) + ver * t) - eye);  // camera.cpp:19-28
+}
+
+// ----------------------------------------------------------- Sample (a12) ----
+// pathTracing.cpp:111-145 (phi drawn first).  asin(sqrt(u)) and acos(u^(1/(Ns+1)))
+// enter only through their sine and cosine.
+TRT_HD inline f3 sampleDir(f3 a, int ray_type, float Ns, float u_phi, float u_theta)
+{
+    float c, s;
+    trt_sincos2pi(u_phi, &c, &s);
+    float sin_t, cos_t;
+    if (ray_type == TRT_RAY_DIFFUSE) {
+        sin_t = sqrtf(u_theta);
+        cos_t = sqrtf(1.0f - u_theta);
+    } else {
+        cos_t = trt_pow01(u_theta, 1.0f / (Ns + 1.0f));
+        const float s2 = 1.0f - cos_t * cos_t;
+        sin_t = sqrtf(s2 > 0.0f ? s2 : 0.0f);
+    }
+    const f3 local = mk3(sin_t * c, cos_t, sin_t * s);
+    f3 front;
+    if (fabsf(a.x) > fabsf(a.y)) front = normalize(mk3(a.z, 0.0f, -a.x));
+    else front = normalize(mk3(0.0f, -a.z, a.y));
+    const f3 right = cross(a, front);
+    return normalize((right * local.x + a * local.y) + front * local.z);
+}
+
+// ---------------------------------------------------------- nextRay (a11) ----
+// pathTracing.cpp:147-209; I = incoming direction.
+TRT_HD inline int nextRay(const MaterialDev& m, f3 pn, f3 I, Stream& rng, f3& out)
+{
+    if (m.Ni > 1.0f) {
+        const float cos_in = dot(I, pn);
+        f3 n;
+        float n1, n2;
+        if (cos_in > 0.0f) { n = -pn; n1 = m.Ni; n2 = 1.0f; }
+        else { n = pn; n1 = 1.0f; n2 = m.Ni; }
+        const float q = (n1 - n2) / (n1 + n2);
+        const float rf0 = q * q;
+        const float x = 1.0f - fabsf(cos_in);
+        const float x2 = x * x;
+        const float fresnel = rf0 + (1.0f - rf0) * ((x2 * x2) * x);
+        if (fresnel < rng.next()) {
+            const f3 T = refract(I, n, n1 / n2);
+            if (T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) { out = T; return TRT_RAY_TRANSMISSION; }
+            out = reflect(I, n);
+            return TRT_RAY_SPECULAR;
+        }
+    }
+    const float Kd_len = length(ld3(m.Kd)), Ks_len = length(ld3(m.Ks));
+    const float kd = Kd_len / (Kd_len + Ks_len), ks = Ks_len / (Kd_len + Ks_len);
+    const float p = rng.next();
+    if (p < kd) {
+        const float u_phi = rng.next(), u_theta = rng.next();
+        out = sampleDir(pn, TRT_RAY_DIFFUSE, m.Ns, u_phi, u_theta);
+        return TRT_RAY_DIFFUSE;
+    }
+    if (m.Ns > 1.0f && p < kd + ks) {
+        const float u_phi = rng.next(), u_theta = rng.next();
+        out = sampleDir(reflect(I, pn), TRT_RAY_SPECULAR, m.Ns, u_phi, u_theta);
+        return TRT_RAY_SPECULAR;
+    }
+    out = mk3(0.f, 0.f, 0.f);
+    return TRT_RAY_INVALID;
+}
+
+// ------------------------------------------------------ path vertex (a5/a8) ----
+struct Vertex {
+    f3 P, pn, wi, Kd;
+    int32_t mat;
+};
+
+// Hit point (bvh.cpp:191), shading normal from the hit's barycentrics
+// (bvh.cpp:223-224; closed form instead of the QR solve of triangle.cpp:12-29),
+// albedo or nearest texel (pathTracing.cpp:15-30).
+TRT_HD inline Vertex makeVertex(const SceneDev& sc, const Hit& h, f3 o, f3 d, const TriShade& ts, const MaterialDev& m)
+{
+    Vertex vx;
+    vx.P = mk3(o.x + d.x * h.t, o.y + d.y * h.t, o.z + d.z * h.t);
+    vx.wi = -d;
+    vx.mat = ts.mat;
+    const float b0 = (1.0f - h.u) - h.v, b1 = h.u, b2 = h.v;
+    vx.pn = normalize((ld3(ts.vn) * b0 + ld3(ts.vn + 3) * b1) + ld3(ts.vn + 6) * b2);
+    if (m.tex >= 0) {
+        const TextureDev tx = sc.textures[m.tex];
+        const float colf = (ts.vt[0] * b0 + ts.vt[2] * b1) + ts.vt[4] * b2;
+        const float rowf = (ts.vt[1] * b0 + ts.vt[3] * b1) + ts.vt[5] * b2;
+        const double col = colf, row = rowf;
+        const double irow = row - floor(row), icol = col - floor(col);
+        int r = (int)(irow * tx.height), c = (int)(icol * tx.width);
+        if (r > tx.height - 1) r = tx.height - 1;
+        if (c > tx.width - 1) c = tx.width - 1;
+        if (r < 0) r = 0;
+        if (c < 0) c = 0;
+        const uint8_t* px = sc.tex_bytes + tx.offset + ((size_t)r * tx.width + c) * 3;
+        vx.Kd = mk3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    } else {
+        vx.Kd = ld3(m.Kd);
+    }
+    return vx;
+}
+
+// One light of shade()'s direct-illumination loop up to, but excluding, the
+// shadow ray (pathTracing.cpp:34-53).  Returns true when a shadow ray must be
+// traced; `wo` is its direction, `contrib` what it adds to L_dir if the closest
+// hit carries the light's material (pathTracing.cpp:55-70).
+TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const MaterialDev& m, uint32_t li, Stream& rng, f3& wo, f3& contrib)
+{
+    const trt_light L = sc.lights[li];
+    const float rnd = rng.next() * sc.light0_area;  // Q3
+    const trt_light_tri* lt = nullptr;
+    for (uint32_t k = 0; k < L.tri_count; ++k)
+        if (rnd < sc.light_tris[L.tri_first + k].cum_area) { lt = &sc.light_tris[L.tri_first + k]; break; }
+    if (!lt) return false;
+    const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
+    const float rs = (r1 + r2) + r3;
+    const float p1 = r1 / rs, p2 = r2 / rs, p3 = r3 / rs;  // Q4
+    const f3 light_p = (ld3(lt->v[0]) * p1 + ld3(lt->v[1]) * p2) + ld3(lt->v[2]) * p3;
+    const f3 light_n = normalize((ld3(lt->vn[0]) * p1 + ld3(lt->vn[1]) * p2) + ld3(lt->vn[2]) * p3);
+    const f3 diff = light_p - vx.P;
+    wo = normalize(diff);
+    const float cos_s = dot(wo, vx.pn);
+    if (!(cos_s > 0.0f)) return false;  // pathTracing.cpp:60: such a sample never contributes
+    const float pdf_light = 1.0f / L.area;
+    const float cos_theta_p = fabsf(dot(wo, light_n));
+    const float cos_theta = fabsf(cos_s / length(vx.pn));
+    const f3 radiance = ld3(L.radiance);
+    const f3 intensity = (((radiance * cos_theta_p) * cos_theta) / dot(diff, diff)) / pdf_light;
+    const f3 hv = normalize((vx.wi + wo) * 0.5f);
+    const float ca = dot(vx.pn, hv);
+    const float cos_alpha = ca > 0.0f ? ca : 0.0f;
+    const float pw = trt_pow01(cos_alpha, m.Ns);
+    const f3 spec = ((ld3(m.Ks) * (m.Ns + 2.0f)) * pw) / (2.0f * TRT_PI);
+    const f3 brdf = vx.Kd / TRT_PI + spec;
+    contrib = intensity * brdf;
+    return true;
+}
+
+// Path-state word carried with every queued ray.
+//   bits 0..15  next RNG draw index        bits 16..17 type of the ray being traced
+//   (3 = camera ray)                       bits 20..31 path depth (vertex index)
+TRT_HD inline uint32_t packMeta(uint32_t ctr, uint32_t type, uint32_t depth) { return (ctr & 0xFFFFu) | ((type & 3u) << 16) | (depth << 20); }
+TRT_HD inline uint32_t metaCtr(uint32_t m) { return m & 0xFFFFu; }
+TRT_HD inline uint32_t metaType(uint32_t m) { return (m >> 16) & 3u; }
+TRT_HD inline uint32_t metaDepth(uint32_t m) { return m >> 20; }
+#define TRT_META_CAMERA 3u
+#define TRT_MAX_PATH_DEPTH 4000u
+
+// ------------------------------------------------ one path vertex: shade() ----
+// Which image rows/pixels a render call covers, and the sample numbering.
+struct TileDesc {
+    const int32_t* rows;  // image row of each packed output row
+    int32_t tile_w, x0, width, height;
+    uint32_t npix;        // rows * tile_w
+    uint32_t seed, spp;
+};
+
+// path id -> (pixel index y*W+x, sample index): id = s_local * npix + pixel-in-tile
+TRT_HD inline trt_rng_key pathKey(const TileDesc& td, uint32_t s0, uint32_t pid)
+{
+    const uint32_t s_local = pid / td.npix, pl = pid - s_local * td.npix;
+    const uint32_t r = pl / (uint32_t)td.tile_w, c = pl - r * (uint32_t)td.tile_w;
+    const uint32_t pixel = (uint32_t)td.rows[r] * (uint32_t)td.width + (uint32_t)(td.x0 + (int)c);
+    return trt_rng_make_key(td.seed, pixel, s0 + s_local);
+}
+
+struct ShadeCtx {
+    bool had_hit;   // the traced ray hit something
+    bool shade_ok;  // ... a non-emissive surface: NEE + continuation follow
+    bool add_L;     // ... an emissive surface whose radiance is kept: Lacc[pid] += addL
+    f3 addL;
+    f3 d, beta;
+    uint32_t pid, depth;
+    Vertex vx;
+    MaterialDev m;
+    Stream rng;
+};
+
+// First part of shade() (pathTracing.cpp:9-30) for the ray (ra, rb, bt) and its hit record.
+TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s0, const f4& ra, const f4& rb, const f4& bt, const f4& hit4, ShadeCtx& c)
+{
+    c.had_hit = c.shade_ok = c.add_L = false;
+    c.addL = mk3(0, 0, 0);
+    c.d = mk3(0, 0, 0);
+    c.beta = mk3(0, 0, 0);
+    c.pid = 0; c.depth = 0;
+    c.vx.P = c.vx.pn = c.vx.wi = c.vx.Kd = mk3(0, 0, 0);
+    c.vx.mat = 0;
+    c.m.Ns = 1.0f; c.m.Ni = 1.0f; c.m.tex = -1; c.m.is_emissive = 0;
+    c.rng.key.k0 = c.rng.key.k1 = 0; c.rng.ctr = 0;
+    Hit h;
+    h.t = hit4.x; h.tri = (int32_t)f2u(hit4.y); h.u = hit4.z; h.v = hit4.w; h.flags = 0;
+    if (h.tri < 0) return;
+    c.had_hit = true;
+    const f3 o = mk3(ra.x, ra.y, ra.z);
+    c.d = mk3(ra.w, rb.x, rb.y);
+    c.beta = mk3(bt.x, bt.y, bt.z);
+    c.pid = f2u(rb.z);
+    const uint32_t meta = f2u(rb.w);
+    c.depth = metaDepth(meta);
+    const TriShade ts = sc.tri_shade[h.tri];
+    c.m = sc.materials[ts.mat];
+    if (c.m.is_emissive) {
+        // pathTracing.cpp:9-12 returns the radiance; the callers keep it for the camera ray
+        // (main.cpp:101) and for TRANSMISSION (pathTracing.cpp:95-96), not after DIFFUSE/SPECULAR (Q9)
+        const uint32_t type = metaType(meta);
+        if (c.depth == 0 || type == TRT_RAY_TRANSMISSION) {
+            const f3 rad = ld3(c.m.radiance);
+            c.add_L = true;
+            c.addL = c.depth == 0 ? rad : c.beta * rad;
+        }
+        return;
+    }
+    c.shade_ok = true;
+    c.vx = makeVertex(sc, h, o, c.d, ts, c.m);
+    c.rng.key = pathKey(td, s0, c.pid);
+    c.rng.ctr = metaCtr(meta);
+}
+
+// Last part of shade() (pathTracing.cpp:78-99): RR(0.8), nextRay, beta update.
+// Returns true when an extension ray leaves the vertex; INVALID rays are not traced.
+TRT_HD inline bool shadeNext(ShadeCtx& c, int max_depth, f4& ra, f4& rb, f4& bt)
+{
+    if (!c.shade_ok) return false;
+    const bool last = (max_depth > 0 && (int)c.depth + 1 >= max_depth) || c.depth + 1 >= TRT_MAX_PATH_DEPTH;
+    if (last || !(c.rng.next() < TRT_P_RR)) return false;  // RR, pathTracing.cpp:104-109
+    f3 nd;
+    const int type = nextRay(c.m, c.vx.pn, c.d, c.rng, nd);
+    if (type == TRT_RAY_INVALID) return false;
+    const f3 w = (type == TRT_RAY_TRANSMISSION) ? ld3(c.m.Tr) : c.vx.Kd;  // Q8: SPECULAR is weighted by Kd too
+    const f3 nb = (c.beta * w) / TRT_P_RR;
+    ra = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, nd.x);  // Q6: origin = hit point, no offset
+    rb = mk4(nd.y, nd.z, u2f(c.pid), u2f(packMeta(c.rng.ctr, (uint32_t)type, c.depth + 1)));
+    bt = mk4(nb.x, nb.y, nb.z, 0.0f);
+    return true;
+}
+
+}  // namespace trtd

@@ -118,6 +118,15 @@ const char* trth_scene_material_name(const trth_scene* s, uint32_t i)
 
 void trth_scene_free(trth_scene* s) { delete s; }
 
+int trth_abi_sizes(int64_t out[12])
+{
+    if (!out) return fail("null argument");
+    out[0] = sizeof(trt_bvh_node); out[1] = sizeof(trt_material); out[2] = sizeof(trt_light); out[3] = sizeof(trt_light_tri);
+    out[4] = sizeof(trt_texture); out[5] = sizeof(trt_camera); out[6] = sizeof(trt_scene); out[7] = sizeof(trt_params);
+    out[8] = sizeof(trt_stats); out[9] = TRT_ABI_VERSION; out[10] = 0; out[11] = 0;
+    return 0;
+}
+
 int trth_tonemap(const float* linear_rgb, int width, int height, uint8_t* out)
 {
     if (!linear_rgb || !out || width <= 0 || height <= 0) return fail("trth_tonemap: bad argument");

@@ -1,0 +1,29 @@
+// render.h — host C++ entry that replaces the body of the reference's main()
+// (main.cpp:74-113): given a loaded Scene it builds the BVH, flattens, and runs
+// the sample/pixel loop on the GPU through the C-ABI (include/trt.h).
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "scene.h"
+#include "trt.h"
+
+namespace trt {
+
+struct RenderOpts {
+    int spp = 256;            // SAMPLE (main.cpp:13)
+    uint32_t seed = 0x5EED0001u;
+    int device = 0;
+    int leaf_num = 8;         // buildBVH(..., 8) at main.cpp:76
+    BvhBuilder builder = BVH_AUTO;
+    int max_depth = 0;
+    uint64_t mem_budget = 0;
+    bool timing = false;
+};
+
+// image: img_width*img_height*3 doubles, zero-initialised by the caller like
+// main.cpp:74-75; the averaged linear radiance is ADDED to it (main.cpp:103-108).
+// Throws std::runtime_error with the library's message on failure.
+void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stats = nullptr);
+
+}  // namespace trt
