@@ -1,0 +1,81 @@
+"""The C-ABI libraries load and export every symbol include/*.h declares (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from tinyraytracing_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    lib = C.CDLL(os.path.join(_abi.LIB_DIR, "libtrt_hip.so"))
+    names = _declared("trt.h", "trt_")
+    assert set(names) == set(_abi.HIP_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = C.CDLL(os.path.join(_abi.LIB_DIR, "libtrt_host.so"))
+    names = _declared("trt_host.h", "trth_")
+    assert set(names) == set(_abi.HOST_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_oracle_exports_every_declared_symbol():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    text = open(os.path.join(ROOT, "oracle", "oracle.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for n in set(re.findall(r"\b(oracle_[a-z0-9_]+)\s*\(", text)):
+        assert hasattr(lib, n), n
+
+
+def test_ctypes_mirror_matches_c_struct_sizes():
+    lib = _abi.load_host()
+    sizes = (C.c_int64 * 12)()
+    assert lib.trth_abi_sizes(sizes) == 0
+    mirror = [_abi.BvhNode, _abi.Material, _abi.Light, _abi.LightTri, _abi.Texture, _abi.Camera, _abi.SceneFlat, _abi.Params, _abi.Stats]
+    assert [int(s) for s in sizes[:9]] == [C.sizeof(m) for m in mirror]
+    assert C.sizeof(_abi.BvhNode) == 64
+    assert sizes[9] == _abi.TRT_ABI_VERSION
+
+
+def test_abi_version_and_rows_selected_without_gpu():
+    lib = _abi.load_hip()
+    assert lib.trt_abi_version() == 1
+    import tinyraytracing_amd as T
+    p = T.make_params(64, 37, 1, 0, rows=(8, 3, 1))
+    assert lib.trt_rows_selected(C.byref(p)) == len(T.rows_selected(p))
+    p = T.make_params(64, 37, 1, 0, tile=(3, 5, 20, 30))
+    assert lib.trt_rows_selected(C.byref(p)) == 25
+
+
+def test_product_has_no_oracle_dependency():
+    """Nothing under tinyraytracing_amd/ or include/ may reference oracle/ or the hostsim."""
+    bad = []
+    for base in ("tinyraytracing_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if not f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                    continue
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"#include\s+[\"<][^\">]*oracle", txt) or re.search(r"^\s*(import|from)\s+oracle", txt, flags=re.M) or "liboracle" in txt or "libhostsim" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_missing_hip_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_abi, "_hip", None)
+    monkeypatch.setattr(_abi, "LIB_DIR", str(tmp_path))
+    with pytest.raises(RuntimeError, match="only compute path"):
+        _abi.load_hip()

@@ -1,0 +1,263 @@
+"""Parity of the HIP path (through the C-ABI of include/trt.h) with the CPU oracle — MI355X only.
+
+Bar: bit-exact.  The formulation makes every fp32 operation of a path the same on both
+sides, so images, hit records and ray counts must be identical; `TOL` below is the stated fp32
+per-pixel tolerance of BASELINE.json's north star and stays at zero unless a test says otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import hostsim_lib as H
+import oracle_lib as O
+import raygen
+import scene_util as SU
+import tinyraytracing_amd as T
+from conftest import get_scene
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 0.0  # max |gpu - oracle| per channel, linear radiance
+
+
+def assert_same_image(a, b, what=""):
+    assert a.shape == b.shape, what
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    assert np.isfinite(a).all(), what
+    assert d.max() <= TOL, f"{what}: max abs diff {d.max()} in {int((d.max(-1) > TOL).sum())} pixels"
+
+
+# ------------------------------------------------------------------ ray batches: traverseBVH
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_trace_matches_golden(name, renderer_factory):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    s = get_scene(name, int(g["width"]), int(g["height"]))
+    r = renderer_factory(s)
+    t, tri, uv = r.trace_closest(g["org"], g["dir"])
+    assert np.array_equal(tri, g["tri"])
+    assert np.array_equal(t, g["t"]) and np.array_equal(uv, g["uv"])
+
+
+@pytest.mark.parametrize("name,n", [("back", 200000), ("staircase", 200000)])
+def test_trace_matches_oracle_on_incoherent_rays(name, n, renderer_factory):
+    s = get_scene(name, 64, 36)
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(n, lo - 5, hi + 5, seed=99)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    t1, tri1, uv1, st = renderer_factory(s).trace_closest(org, dirs, want_stats=True)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+    # the kernel runs the same traversal as the hostsim: identical visit counts
+    _, _, _, cnt = H.trace(s.flat, org, dirs)
+    assert [st.inner_visits[0], st.tri_tests[0]] == cnt
+
+
+def test_trace_soup_deep_bvh(renderer_factory):
+    s = get_scene("soup", 64, 36, n=200000)
+    assert s.arrays()["bvh_depth"] > 12
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(100000, lo, hi, seed=5)
+    o2, d2 = raygen.primary_rays(s, 64, 36)
+    org, dirs = np.vstack([org, o2]), np.vstack([dirs, d2])
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    t1, tri1, uv1 = renderer_factory(s).trace_closest(org, dirs)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+
+
+# ------------------------------------------------------------------ images: the whole loop
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_image_matches_golden(name, renderer_factory):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    w, h, spp, seed = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])
+    s = get_scene(name, w, h)
+    img, st = renderer_factory(s).render(T.make_params(w, h, spp, seed))
+    assert_same_image(img, g["image"], name)
+    assert [st.rays_camera, st.rays_shadow, st.rays_indirect] == g["rays"].tolist()
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("back", 128, 128, 32), ("veach-mis", 160, 90, 16), ("staircase", 160, 90, 16)])
+def test_image_matches_oracle(name, w, h, spp, renderer_factory):
+    s = get_scene(name, w, h)
+    p = T.make_params(w, h, spp, 0xABCDEF, flags=T.TRT_FLAG_COUNT | T.TRT_FLAG_TIMING)
+    img, st = renderer_factory(s).render(p)
+    ref, ost = O.render(s.flat, p)
+    assert_same_image(img, ref, name)
+    assert (st.rays_camera, st.rays_shadow, st.rays_indirect, st.shaded_hits) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect, ost.shaded_hits)
+    assert st.max_bounces == ost.max_bounces
+    assert st.inner_visits[0] > 0 and st.tri_tests[0] > 0 and st.inner_visits[1] > 0
+    assert st.kernel_ms[1] > 0 and st.render_ms > 0
+
+
+def test_sample_chunking_is_invisible(renderer_factory):
+    """A small mem_budget splits the spp into several passes; the result must not change."""
+    s = get_scene("back", 96, 96)
+    r = renderer_factory(s)
+    big, st_big = r.render(T.make_params(96, 96, 24, 3))
+    per_path = 2 * 48 + 16 + 16 + 48
+    small, st_small = r.render(T.make_params(96, 96, 24, 3, mem_budget=96 * 96 * 5 * per_path))
+    assert st_big.passes == 1 and st_small.passes == 5
+    assert np.array_equal(big, small)
+    assert st_big.rays == st_small.rays
+
+
+def test_tiles_and_row_interleave_compose(renderer_factory):
+    s = get_scene("back", 100, 60)
+    r = renderer_factory(s)
+    full, _ = r.render(T.make_params(100, 60, 6, 17))
+    parts = np.zeros_like(full)
+    for k in range(3):
+        p = T.make_params(100, 60, 6, 17, rows=(8, 3, k))
+        out, st = r.render(p)
+        ys = T.rows_selected(p)
+        assert st.rows_rendered == len(ys)
+        parts[ys] = out
+    assert np.array_equal(full, parts)
+    tile, _ = r.render(T.make_params(100, 60, 6, 17, tile=(13, 7, 77, 41)))
+    assert np.array_equal(tile, full[7:41, 13:77])
+    one, _ = r.render(T.make_params(100, 60, 6, 17, tile=(50, 30, 51, 31)))
+    assert np.array_equal(one, full[30:31, 50:51])
+
+
+def test_render_into_device_tensor(renderer_factory):
+    import torch
+    s = get_scene("back", 64, 64)
+    r = renderer_factory(s)
+    p = T.make_params(64, 64, 4, 1)
+    host, _ = r.render(p)
+    out = torch.empty((64, 64, 3), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        st = r.render_into(p, out, stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host) and st.rays > 0
+
+
+# ------------------------------------------------------------------ BASELINE.json sizes, size-independent properties
+def test_config2_full_size_tile_vs_oracle_and_determinism(renderer_factory):
+    """Config 2: back, 1024x1024, 256 spp.  The streams are keyed by the global (pixel, sample), so a
+    tile cut out of the full-size render equals the oracle's render of just that tile; the full render
+    is also reproducible bit for bit and equals the union of 8 interleaved stripes."""
+    s = get_scene("back", 1024, 1024)
+    r = renderer_factory(s)
+    p = T.make_params(1024, 1024, 256, T.SEED_BACK)
+    full, st = r.render(p)
+    assert np.isfinite(full).all() and st.rays_camera == 1024 * 1024 * 256
+    for (x0, y0) in ((500, 500), (40, 900), (1000, 8)):
+        pt = T.make_params(1024, 1024, 256, T.SEED_BACK, tile=(x0, y0, x0 + 12, y0 + 12))
+        ref, _ = O.render(s.flat, pt)
+        assert_same_image(full[y0:y0 + 12, x0:x0 + 12], ref, f"tile {x0},{y0}")
+    again, st2 = r.render(p)
+    assert np.array_equal(full, again) and st.rays == st2.rays
+    # converged image statistics vs the reference's own snapshots of this scene (+-30 %)
+    lin = (T.tonemap(full).astype(np.float64) / 255) ** 2.2
+    mean = lin.reshape(-1, 3).mean(0)
+    ref_mean = np.array([(0.220 + 0.237) / 2, (0.218 + 0.243) / 2, (0.071 + 0.098) / 2])
+    assert np.all(np.abs(mean / ref_mean - 1) < 0.30), mean
+
+
+def test_config2_stripes_union(renderer_factory):
+    s = get_scene("back", 1024, 1024)
+    r = renderer_factory(s)
+    full, _ = r.render(T.make_params(1024, 1024, 32, T.SEED_BACK))
+    parts = np.empty_like(full)
+    for k in range(8):
+        p = T.make_params(1024, 1024, 32, T.SEED_BACK, rows=(8, 8, k))
+        parts[T.rows_selected(p)] = r.render(p)[0]
+    assert np.array_equal(full, parts)
+
+
+def test_config3_soup_tile_vs_oracle(renderer_factory):
+    """Config 3 (deep-BVH stress) at reduced triangle count for the CPU checker: 1920x1080, 64 spp."""
+    s = get_scene("soup", 1920, 1080, n=300000)
+    r = renderer_factory(s)
+    for (x0, y0) in ((960, 540), (100, 1000)):
+        pt = T.make_params(1920, 1080, 64, T.SEED_SOUP, tile=(x0, y0, x0 + 16, y0 + 8))
+        img, st = r.render(pt)
+        ref, ost = O.render(s.flat, pt)
+        assert_same_image(img, ref, f"soup tile {x0},{y0}")
+        assert st.rays == ost.rays
+
+
+# ------------------------------------------------------------------ edge cases and error behaviour
+def test_empty_and_single_triangle_scenes(tmp_path):
+    SU.write_scene(tmp_path, "empty", "v 0 0 0\n", SU.MTL_BASIC, w=16, h=16)
+    s = SU.load(tmp_path, "empty")
+    assert s.info["n_triangles"] == 0
+    r = T.Renderer(s, 0)
+    img, st = r.render(T.make_params(16, 16, 2, 1))
+    assert not img.any() and st.rays == 16 * 16 * 2 and st.shaded_hits == 0
+    t, tri, uv = r.trace_closest(np.zeros((5, 3), np.float32), np.tile(np.array([0, 0, -1], np.float32), (5, 1)))
+    assert (tri == -1).all() and (t == np.float32(T._abi.TRT_INF)).all()
+    r.close()
+    one = "v -1 -1 0\nv 1 -1 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nusemtl lamp\nf 1/1/1 2/1/1 3/1/1\n"
+    SU.write_scene(tmp_path, "one", one, SU.MTL_BASIC, lights=[("lamp", (3, 2, 1))], w=16, h=16)
+    s1 = SU.load(tmp_path, "one")
+    r1 = T.Renderer(s1, 0)
+    p = T.make_params(16, 16, 4, 2)
+    img, st = r1.render(p)
+    ref, _ = O.render(s1.flat, p)
+    assert np.array_equal(img, ref) and img.max() == 3.0     # camera rays return the raw radiance (pathTracing.cpp:9-12)
+    r1.close()
+
+
+def test_glass_specular_texture_scene(tmp_path, renderer_factory):
+    """All lobes at once: TRANSMISSION / TIR through a glass slab, Phong lobe, two lights (Q3 CDF quirk)."""
+    v = ["vt 0 0", "vt 1 0", "vt 1 1", "vt 0 1", "vn 0 1 0", "vn 0 -1 0", "vn 0 0 1"]
+    obj = "\n".join(v) + "\n"
+    verts = ["-4 0 -4", "4 0 -4", "4 0 4", "-4 0 4",          # floor (shiny)
+             "-1 3 -1", "1 3 -1", "1 3 1", "-1 3 1",           # lamp A
+             "2 2.5 -0.3", "2.6 2.5 -0.3", "2.6 2.5 0.3", "2 2.5 0.3",   # lamp B (smaller)
+             "-1.5 0.8 -1.5", "1.5 0.8 -1.5", "1.5 0.8 1.5", "-1.5 0.8 1.5",   # glass slab top
+             "-1.5 0.5 -1.5", "1.5 0.5 -1.5", "1.5 0.5 1.5", "-1.5 0.5 1.5"]   # glass slab bottom
+    obj += "\n".join("v " + x for x in verts) + "\n"
+    obj += "usemtl shiny\nf 1/1/5 3/3/5 2/2/5\nf 1/1/5 4/4/5 3/3/5\n"
+    obj += "usemtl lamp\nf 5/1/6 6/2/6 7/3/6\nf 5/1/6 7/3/6 8/4/6\n"
+    obj += "usemtl lamp2\nf 9/1/6 10/2/6 11/3/6\nf 9/1/6 11/3/6 12/4/6\n"
+    obj += "usemtl glass\nf 13/1/5 15/3/5 14/2/5\nf 13/1/5 16/4/5 15/3/5\nf 17/1/6 18/2/6 19/3/6\nf 17/1/6 19/3/6 20/4/6\n"
+    mtl = SU.MTL_BASIC + "newmtl lamp2\nKd 0 0 0\nKs 0 0 0\nNs 1\nNi 1\n"
+    SU.write_scene(tmp_path, "mix", obj, mtl, lights=[("lamp", (20, 20, 20)), ("lamp2", (40, 30, 20))], w=64, h=48, fovy=45, eye=(0, 2.2, 6), lookat=(0, 0.6, 0))
+    s = SU.load(tmp_path, "mix")
+    r = T.Renderer(s, 0)
+    p = T.make_params(64, 48, 32, 11)
+    img, st = r.render(p)
+    ref, ost = O.render(s.flat, p)
+    assert_same_image(img, ref, "mix")
+    assert st.rays == ost.rays and st.rays_indirect > 0
+    r.close()
+
+
+def test_error_codes(renderer_factory):
+    s = get_scene("back", 64, 64)
+    r = renderer_factory(s)
+    lib = T._abi.load_hip()
+    out = np.zeros((64, 64, 3), np.float32)
+    fp = out.ctypes.data_as(C.POINTER(C.c_float))
+    for bad in (T.make_params(64, 64, 0, 1), T.make_params(1, 64, 1, 1), T.make_params(64, 64, 1, 1, tile=(0, 0, 65, 64)),
+                T.make_params(64, 64, 1, 1, tile=(10, 10, 10, 20)), T.make_params(64, 64, 1, 1, rows=(0, 2, 0)),
+                T.make_params(64, 64, 1, 1, rows=(8, 2, 2)), T.make_params(64, 64, 1, 1, max_depth=-1)):
+        rc = lib.trt_render(r._h, C.byref(bad), fp, None)
+        assert rc == 1 and lib.trt_last_error()               # TRT_EINVAL + message, never exit()
+    assert lib.trt_render(r._h, C.byref(T.make_params(64, 64, 1, 1)), None, None) == 1
+    tiny = T.make_params(64, 64, 1, 1, mem_budget=1000)
+    assert lib.trt_render(r._h, C.byref(tiny), fp, None) == 3    # TRT_ENOMEM: budget below one sample per pixel
+    h = C.c_void_p()
+    assert lib.trt_create(None, 0, C.byref(h)) == 1
+    assert lib.trt_create(s.flat, 99, C.byref(h)) == 4           # TRT_ENODEV
+    # a corrupted BVH is rejected on the host, before any kernel could chase a bad index
+    from tinyraytracing_amd._abi import BvhNode, SceneFlat
+    f = s.flat.contents
+    g = SceneFlat()
+    C.memmove(C.byref(g), C.byref(f), C.sizeof(SceneFlat))
+    nodes = (BvhNode * f.n_nodes)()
+    C.memmove(nodes, f.nodes, C.sizeof(BvhNode) * f.n_nodes)
+    nodes[0].child0 = 12345
+    g.nodes = nodes
+    assert lib.trt_create(C.byref(g), 0, C.byref(h)) == 1 and b"bvh" in lib.trt_last_error()
+    nodes[0].child0 = 0                                          # a cycle
+    assert lib.trt_create(C.byref(g), 0, C.byref(h)) == 1
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

@@ -1,0 +1,73 @@
+"""CPU check of the DEVICE-SIDE code: tinyraytracing_amd/csrc/trt_path.h (ordered, culled stack
+traversal; shadeBegin / lightSample / shadeNext as the wavefront kernels call them) compiled with
+g++ (tests/hostsim) must reproduce the oracle — which traverses recursively, unordered and unculled
+like bvh.cpp:146-175 — bit for bit, and the committed golden fixtures too."""
+import os
+
+import numpy as np
+import pytest
+
+import hostsim_lib as H
+import oracle_lib as O
+import raygen
+import tinyraytracing_amd as T
+from conftest import get_scene
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_oracle_reproduces_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    w, h, spp, seed = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])
+    s = get_scene(name, w, h)
+    img, st = O.render(s.flat, T.make_params(w, h, spp, seed))
+    assert np.array_equal(img, g["image"])
+    assert [st.rays_camera, st.rays_shadow, st.rays_indirect] == g["rays"].tolist()
+    t, tri, uv = O.trace(s.flat, g["org"], g["dir"])
+    assert np.array_equal(t, g["t"]) and np.array_equal(tri, g["tri"]) and np.array_equal(uv, g["uv"])
+
+
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_device_code_on_cpu_matches_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    w, h, spp, seed = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])
+    s = get_scene(name, w, h)
+    img, rays = H.render(s.flat, T.make_params(w, h, spp, seed))
+    assert np.array_equal(img, g["image"])
+    assert rays == g["rays"].tolist()
+    t, tri, uv, cnt = H.trace(s.flat, g["org"], g["dir"])
+    assert np.array_equal(t, g["t"]) and np.array_equal(tri, g["tri"]) and np.array_equal(uv, g["uv"])
+
+
+def test_ordered_culled_traversal_visits_less_but_finds_the_same():
+    s = get_scene("staircase", 64, 36)
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(20000, lo, hi, seed=21)
+    t0, tri0, uv0, st = O.trace(s.flat, org, dirs, want_stats=True)
+    t1, tri1, uv1, cnt = H.trace(s.flat, org, dirs)
+    assert np.array_equal(t0, t1) and np.array_equal(tri0, tri1) and np.array_equal(uv0, uv1)
+    assert cnt[0] < st.inner_visits[0] and cnt[1] < st.tri_tests[0]
+
+
+def test_device_code_on_synthetic_soup_and_tiles():
+    s = T.Scene.named("soup", 48, 27, n=20000)
+    p = T.make_params(48, 27, 4, T.SEED_SOUP)
+    a, sa = O.render(s.flat, p)
+    b, rays = H.render(s.flat, p)
+    assert np.array_equal(a, b) and rays == [sa.rays_camera, sa.rays_shadow, sa.rays_indirect]
+    # tiles and row interleave address the same (pixel, sample) streams
+    pt = T.make_params(48, 27, 4, T.SEED_SOUP, tile=(8, 3, 40, 20), rows=(2, 3, 1))
+    c, _ = H.render(s.flat, pt)
+    assert np.array_equal(c, a[T.rows_selected(pt)][:, 8:40])
+
+
+def test_max_depth_and_one_spp():
+    s = get_scene("back", 32, 32)
+    for md in (1, 2, 5):
+        p = T.make_params(32, 32, 1, 5, max_depth=md)
+        a, sa = O.render(s.flat, p)
+        b, rays = H.render(s.flat, p)
+        assert np.array_equal(a, b)
+        assert sa.max_bounces <= md - 1 and rays[2] == sa.rays_indirect
+    assert O.render(s.flat, T.make_params(32, 32, 1, 5, max_depth=1))[1].rays_indirect == 0

@@ -1,0 +1,172 @@
+"""Host loaders / BVH builder / PNG output (reference: scene.cpp:3-213, camera.cpp:3-17,
+bvh.cpp:16-144, main.cpp:19-42).  Expected counts and areas are the ones SURVEY.md §8c(7)
+and §8a Q3 record for the shipped scenes."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import scene_util as SU
+import tinyraytracing_amd as T
+from conftest import get_scene
+
+
+def test_back_counts_and_light():
+    s = get_scene("back", 64, 64)
+    i = s.info
+    assert (i["n_vertices"], i["n_vt"], i["n_vn"], i["n_triangles"]) == (36, 42, 66, 26)
+    assert i["n_lights"] == 1 and i["n_materials"] == 4
+    assert abs(s.light_area(0) - 27300.0) < 1e-6
+    f = s.flat.contents
+    assert f.n_light_tris == 4 and f.lights[0].tri_count == 4
+    # cumulative CDF (Triangle::area, scene.cpp:203): 4 equal triangles of 6825
+    cum = [f.light_tris[k].cum_area for k in range(4)]
+    assert np.allclose(cum, [6825, 13650, 20475, 27300], rtol=1e-6)
+    assert tuple(f.lights[0].radiance) == (34.0, 24.0, 8.0)
+    m = f.materials[f.lights[0].mat]
+    assert m.is_emissive == 1 and tuple(m.radiance) == (34.0, 24.0, 8.0)
+    # back.mtl writes Kt, which the loader ignores: Tr stays 0
+    names = [s.material_name(k) for k in range(4)]
+    w = f.materials[names.index("back:DiffuseWhite")]
+    assert np.allclose(tuple(w.Kd), (0.79, 0.76, 0.73)) and tuple(w.Tr) == (0, 0, 0) and w.Ns == 1 and w.Ni == 1
+
+
+def test_veach_counts_and_light_areas():
+    s = get_scene("veach-mis", 64, 36)
+    i = s.info
+    assert (i["n_vertices"], i["n_vt"], i["n_vn"], i["n_triangles"]) == (1421, 1421, 1421, 2332)
+    assert i["n_lights"] == 3
+    areas = [s.light_area(k) for k in range(3)]
+    assert np.allclose(areas, [0.0311, 3.106, 12.43], rtol=2e-2)
+    assert s.flat.contents.n_light_tris == 760 * 3
+
+
+def test_staircase_counts_lights_textures():
+    s = get_scene("staircase", 64, 36)
+    i = s.info
+    assert (i["n_vertices"], i["n_vt"], i["n_vn"], i["n_triangles"]) == (19350, 19350, 19350, 31407)
+    assert i["n_lights"] == 6
+    areas = [s.light_area(k) for k in range(6)]
+    assert np.allclose(areas, [0.182, 0.062, 517, 36.4, 15.6, 124], rtol=2e-2)
+    f = s.flat.contents
+    assert f.n_textures == 3
+    dims = sorted((f.textures[k].width, f.textures[k].height) for k in range(3))
+    assert dims == [(512, 512), (894, 894), (1600, 1200)]
+    # multi-line radiance attribute (staircase.xml:10-12)
+    assert np.allclose(tuple(f.lights[3].radiance), (2.742004577636719, 2.1547576084136963, 0.9237708320617676))
+    glass = [k for k in range(i["n_materials"]) if s.material_name(k) == "Glass"][0]
+    assert f.materials[glass].Ni == 1.5 and np.allclose(tuple(f.materials[glass].Tr), (0.8, 1.0, 0.95))
+
+
+def test_texture_sidecar_matches_pil_decode():
+    s = get_scene("staircase", 64, 36)
+    f = s.flat.contents
+    for k in range(3):
+        tx = f.textures[k]
+        if (tx.width, tx.height) == (512, 512):
+            ref = np.asarray(Image.open(os.path.join(T.SCENES_DIR, "staircase", "textures", "Wallpaper.jpg")).convert("RGB"))
+            got = np.ctypeslib.as_array(tx.rgb, shape=(tx.height, tx.width, 3))
+            assert np.array_equal(ref, got)
+
+
+def test_camera_setup_and_resolution_override():
+    s = get_scene("back", 1024, 1024)
+    c = s.flat.contents.camera
+    # camera.cpp:3-17 for the Cornell camera: w = (0,0,-1), u = (-1,0,0), v = (0,1,0)
+    h = np.tan(np.radians(np.float64(np.float32(39.3077))) / 2)
+    vh = np.float32(2 * h)
+    assert np.allclose(tuple(c.eye), (278, 273, -800))
+    assert np.allclose(tuple(c.vertical), (0, vh, 0), atol=1e-6)
+    assert np.allclose(tuple(c.horizontal), (-vh, 0, 0), atol=1e-6)
+    assert np.allclose(tuple(c.lower_left_corner), (278 + vh / 2, 273 - vh / 2, -799), atol=1e-4)
+    wide = get_scene("back", 1920, 1080).flat.contents.camera
+    assert np.isclose(abs(wide.horizontal[0]) / wide.vertical[1], 1920 / 1080, rtol=1e-6)  # aspect recomputed (scene.cpp:15)
+
+
+def test_bvh_is_well_formed_for_both_builders():
+    for builder in ("sweep", "binned"):
+        s = T.Scene.named("staircase", 64, 36, builder=builder)
+        f = s.flat.contents
+        seen = np.zeros(f.n_tris, bool)
+        stack, depth, visited = [(0, 1)], 0, 0
+        while stack:
+            n, d = stack.pop()
+            visited += 1
+            depth = max(depth, d)
+            nd = f.nodes[n]
+            for ref, lo, hi in ((nd.child0, nd.lo0, nd.hi0), (nd.child1, nd.lo1, nd.hi1)):
+                if ref & 0x80000000:
+                    first, cnt = ref & 0x07FFFFFF, (ref >> 27) & 15
+                    assert 1 <= cnt <= 8
+                    assert not seen[first:first + cnt].any()
+                    seen[first:first + cnt] = True
+                    v = np.ctypeslib.as_array(f.tri_v, shape=(f.n_tris, 3, 3))[first:first + cnt].reshape(-1, 3)
+                    # padded by 0.001 (bvh.cpp:31-40)
+                    assert np.all(v.min(0) - 0.001 >= np.array(lo) - 1e-6) and np.all(v.max(0) + 0.001 <= np.array(hi) + 1e-6)
+                else:
+                    assert 0 < ref < f.n_nodes
+                    stack.append((ref, d + 1))
+        assert seen.all() and visited == f.n_nodes and depth == f.bvh_depth
+
+
+def test_obj_slot_order_quirk_and_extensions(tmp_path):
+    """scene.cpp:149-152: `vt` seen before any `vn` -> tokens are v/vt/vn, otherwise v/vn/vt."""
+    verts = "v 0 0 0\nv 1 0 0\nv 0 1 0\n"
+    std = verts + "vt 0.25 0.75\nvn 0 0 1\nusemtl white\nf 1/1/1 2/1/1 3/1/1\n"
+    swapped = verts + "vn 0 0 1\nvt 0.25 0.75\nusemtl white\nf 1/1/1 2/1/1 3/1/1\n"
+    for name, text in (("std", std), ("swapped", swapped)):
+        SU.write_scene(tmp_path, name, text, SU.MTL_BASIC)
+        s = SU.load(tmp_path, name)
+        a = s.arrays()
+        assert np.allclose(a["tri_vn"][0], [[0, 0, 1]] * 3) and np.allclose(a["tri_vt"][0], [[0.25, 0.75]] * 3)
+    # accepted beyond the reference: v//vn, bare v (face normal), negative indices; only the first 3 tokens of a face are used
+    ext = verts + "v 1 1 0\nvn 0 0 1\nusemtl white\nf 1//1 2//1 3//1\nf 1 2 3 4\nf -4//-1 -3//-1 -2//-1\n"
+    SU.write_scene(tmp_path, "ext", ext, SU.MTL_BASIC)
+    s = SU.load(tmp_path, "ext")
+    assert s.info["n_triangles"] == 3
+    assert np.allclose(s.arrays()["tri_vn"][:, :, 2], 1.0)
+
+
+def test_loader_errors_are_reported_not_fatal(tmp_path):
+    with pytest.raises(T.TrtError, match="failed"):
+        T.Scene.load(str(tmp_path / "nope.xml"), "x.obj", "x.mtl", str(tmp_path))
+    SU.write_scene(tmp_path, "bad", "v 0 0 0\nusemtl white\nf 1/1/1 2/1/1 3/1/1\n", SU.MTL_BASIC)
+    with pytest.raises(T.TrtError, match="out of range"):
+        SU.load(tmp_path, "bad")
+    with pytest.raises(T.TrtError):
+        T.Scene.named("back", 64, 64, leaf_num=16)
+
+
+def test_tonemap_matches_reference_transfer():
+    x = np.array([[[0.0, 1.0, 0.5], [2.0, 0.001, 0.2176]]], np.float32)
+    got = T.tonemap(x)
+    exp = np.clip(np.power(x.astype(np.float64), np.float64(np.float32(1.0) / np.float32(2.2))) * 255, 0, 255).astype(np.uint8)  # main.cpp:34
+    assert np.array_equal(got, exp)
+    assert got[0, 0, 1] == 255 and got[0, 1, 0] == 255
+
+
+def test_png_writer_roundtrip(tmp_path):
+    rng = np.random.default_rng(3)
+    for (h, w) in ((1, 1), (7, 13), (200, 333)):   # the last one spans several 64 KiB stored blocks
+        img = rng.random((h, w, 3)).astype(np.float32)
+        path = str(tmp_path / f"t{h}x{w}.png")
+        T.imshow(img, path)
+        back = np.asarray(Image.open(path))
+        assert back.shape == (h, w, 3) and np.array_equal(back, T.tonemap(img))
+
+
+def test_synthetic_scenes_build():
+    s = T.Scene.named("soup", 64, 36, n=5000)
+    assert s.info["n_triangles"] == 26 - 12 + 5000
+    v = s.arrays()["tri_v"]
+    assert np.isfinite(v).all()
+    b = T.Scene.named("blob", 64, 36, n=2000)
+    n = b.info["n_triangles"] - 14
+    assert n >= 2000 and n % 20 == 0
+    vn = b.arrays()["tri_vn"]
+    assert np.allclose(np.linalg.norm(vn.reshape(-1, 3), axis=1), 1.0, atol=1e-4)
+    # deterministic
+    s2 = T.Scene.named("soup", 64, 36, n=5000)
+    assert np.array_equal(np.sort(s.arrays()["tri_v"].reshape(-1)), np.sort(s2.arrays()["tri_v"].reshape(-1)))

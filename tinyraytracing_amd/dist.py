@@ -1,0 +1,93 @@
+"""Image tiling across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  Every
+(pixel, sample) of the image is independent given the read-only scene
+(main.cpp:84-108 has no cross-pixel dependency), so the scene is replicated and
+the image rows are dealt to the ranks in interleaved stripes of `row_block`
+rows: rank r renders the rows y with (y // row_block) % world == r.  Because
+the RNG stream is keyed by the global (pixel, sample), the assembled image is
+bit-identical for every world size.  The only communication is ONE gather of
+the packed float32 stripes to rank 0 over xGMI.
+"""
+import numpy as np
+
+from . import make_params, rows_selected
+
+ROW_BLOCK = 8
+
+
+def shard_params(width, height, spp, seed, rank, world, row_block=ROW_BLOCK, **kw):
+    """Params of the rows this rank renders."""
+    return make_params(width, height, spp, seed, rows=(row_block, world, rank) if world > 1 else None, **kw)
+
+
+def max_rows(width, height, world, row_block=ROW_BLOCK):
+    """Rows of the most loaded rank (the gather uses equal-sized, padded buffers)."""
+    if world <= 1:
+        return height
+    best = 0
+    for r in range(world):
+        n = sum(1 for y in range(height) if (y // row_block) % world == r)
+        best = max(best, n)
+    return best
+
+
+def assemble(stripes, width, height, world, row_block=ROW_BLOCK):
+    """Un-interleaves per-rank packed stripes [world][rows_r, width, 3] into the full image."""
+    img = np.empty((height, width, 3), np.float32)
+    for r in range(world):
+        p = make_params(width, height, 1, 0, rows=(row_block, world, r) if world > 1 else None)
+        ys = rows_selected(p)
+        img[ys] = np.asarray(stripes[r])[: len(ys)]
+    return img
+
+
+_row_index_cache = {}
+
+
+def _row_indices(width, height, world, row_block, device):
+    """Per rank: LongTensor of the image rows it owns (cached; used to un-interleave on the device)."""
+    import torch
+    key = (height, world, row_block, str(device))
+    if key not in _row_index_cache:
+        idx = []
+        for r in range(world):
+            p = make_params(width, height, 1, 0, rows=(row_block, world, r) if world > 1 else None)
+            idx.append(torch.tensor(rows_selected(p), dtype=torch.long, device=device))
+        _row_index_cache[key] = idx
+    return _row_index_cache[key]
+
+
+def render_distributed(render_fn, width, height, spp, seed, dist=None, device=None, row_block=ROW_BLOCK, **kw):
+    """Renders this rank's stripes with `render_fn(params) -> (array-or-tensor [rows, width, 3], stats)`
+    and gathers them on rank 0.  Returns (image tensor [height, width, 3] on rank 0 else None, stats of
+    this rank).  The image stays where the gather ran: on the GPU with RCCL (`device` given, backend
+    nccl), on the CPU with gloo.
+
+    `dist` is torch.distributed (already initialised) or None for a single process."""
+    import torch
+
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    p = shard_params(width, height, spp, seed, rank, world, row_block, **kw)
+    out, stats = render_fn(p)
+    t = out if torch.is_tensor(out) else torch.from_numpy(np.ascontiguousarray(out))
+    if device is not None:
+        t = t.to(device)
+    if world == 1:
+        return t.reshape(height, width, 3), stats
+    pad_rows = max_rows(width, height, world, row_block)
+    nrows = t.numel() // (width * 3)
+    if nrows == pad_rows:
+        buf = t.reshape(pad_rows, width, 3)
+    else:
+        buf = torch.zeros((pad_rows, width, 3), dtype=torch.float32, device=t.device)
+        buf[:nrows] = t.reshape(nrows, width, 3)
+    gather_list = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gather_list, dst=0)  # the single collective of the data path
+    if rank != 0:
+        return None, stats
+    img = torch.empty((height, width, 3), dtype=torch.float32, device=t.device)
+    for r, idx in enumerate(_row_indices(width, height, world, row_block, t.device)):
+        img.index_copy_(0, idx, gather_list[r][: idx.numel()])
+    return img, stats

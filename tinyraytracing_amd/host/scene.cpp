@@ -374,8 +374,11 @@ void Scene::readobj(const std::string& obj_path)
                 long idx[3];
                 parseFaceToken(tok[k], idx);
                 tri.v[k] = pick(vertices, idx[0], "vertex");
-                const long i_vn = second_slot_is_vn ? idx[1] : idx[2];
-                const long i_vt = second_slot_is_vn ? idx[2] : idx[1];
+                // The slot-order quirk applies to the full a/b/c form the reference parses; the
+                // forms it cannot parse follow the OBJ standard: a//c = v//vn, a/b = v/vt.
+                const bool full = idx[1] != 0 && idx[2] != 0;
+                const long i_vn = (full && second_slot_is_vn) ? idx[1] : idx[2];
+                const long i_vt = (full && second_slot_is_vn) ? idx[2] : idx[1];
                 if (i_vn != 0) tri.vn[k] = pick(vn, i_vn, "normal"); else have_vn = false;
                 if (i_vt != 0) tri.vt[k] = pick(vt, i_vt, "texcoord");
             }
