@@ -211,10 +211,10 @@ def test_glass_specular_texture_scene(tmp_path, renderer_factory):
              "-1.5 0.8 -1.5", "1.5 0.8 -1.5", "1.5 0.8 1.5", "-1.5 0.8 1.5",   # glass slab top
              "-1.5 0.5 -1.5", "1.5 0.5 -1.5", "1.5 0.5 1.5", "-1.5 0.5 1.5"]   # glass slab bottom
     obj += "\n".join("v " + x for x in verts) + "\n"
-    obj += "usemtl shiny\nf 1/1/5 3/3/5 2/2/5\nf 1/1/5 4/4/5 3/3/5\n"
-    obj += "usemtl lamp\nf 5/1/6 6/2/6 7/3/6\nf 5/1/6 7/3/6 8/4/6\n"
-    obj += "usemtl lamp2\nf 9/1/6 10/2/6 11/3/6\nf 9/1/6 11/3/6 12/4/6\n"
-    obj += "usemtl glass\nf 13/1/5 15/3/5 14/2/5\nf 13/1/5 16/4/5 15/3/5\nf 17/1/6 18/2/6 19/3/6\nf 17/1/6 19/3/6 20/4/6\n"
+    obj += "usemtl shiny\nf 1/1/1 3/3/1 2/2/1\nf 1/1/1 4/4/1 3/3/1\n"
+    obj += "usemtl lamp\nf 5/1/2 6/2/2 7/3/2\nf 5/1/2 7/3/2 8/4/2\n"
+    obj += "usemtl lamp2\nf 9/1/2 10/2/2 11/3/2\nf 9/1/2 11/3/2 12/4/2\n"
+    obj += "usemtl glass\nf 13/1/1 15/3/1 14/2/1\nf 13/1/1 16/4/1 15/3/1\nf 17/1/2 18/2/2 19/3/2\nf 17/1/2 19/3/2 20/4/2\n"
     mtl = SU.MTL_BASIC + "newmtl lamp2\nKd 0 0 0\nKs 0 0 0\nNs 1\nNi 1\n"
     SU.write_scene(tmp_path, "mix", obj, mtl, lights=[("lamp", (20, 20, 20)), ("lamp2", (40, 30, 20))], w=64, h=48, fovy=45, eye=(0, 2.2, 6), lookat=(0, 0.6, 0))
     s = SU.load(tmp_path, "mix")

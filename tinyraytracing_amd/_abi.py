@@ -121,11 +121,33 @@ def load_host():
     return lib
 
 
+def _bind_to_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7) and load it through the unversioned name, so a process that had already loaded
+    /opt/rocm's copy for libtrt_hip.so would end up with two runtimes and torch would then see no GPU.
+    When a torch installation is present its copy is loaded first (by path, RTLD_GLOBAL, without
+    importing torch); libtrt_hip.so's NEEDED libamdhip64.so.7 then resolves to it by SONAME, and torch
+    later finds the same file again.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
 def load_hip():
     """Loads the HIP C-ABI library.  Raises loudly if it is absent: the hot path has no fallback."""
     global _hip
     if _hip is not None:
         return _hip
+    _bind_to_torch_hip_runtime()
     path = os.path.join(LIB_DIR, "libtrt_hip.so")
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP extension is the only compute path; "
