@@ -20,7 +20,7 @@ HOST_HDR := $(wildcard $(PKG)/host/*.h) include/trt.h include/trt_host.h include
 HIP_SRC := $(PKG)/csrc/trt_api.hip
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h
 
-.PHONY: all host hip oracle cli hostsim clean
+.PHONY: all host hip oracle cli hostsim variants clean
 all: host hip oracle hostsim cli
 
 host: $(OUT)/libtrt_host.so
@@ -43,6 +43,13 @@ $(OUT)/libtrt_hip.so: $(HIP_SRC) $(HIP_HDR)
 
 $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -Wl,-rpath,'$$ORIGIN'
+
+# A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
+variants: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(OUT)/variants
+	$(HIPCC) $(HIPFLAGS) -DTRT_PREFETCH=0 -shared -o $(OUT)/variants/libtrt_hip_nopf.so $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -DTRT_PREFETCH=0 -DTRT_TRACE_MINWAVES=8 -shared -o $(OUT)/variants/libtrt_hip_nopf_w8.so $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -DTRT_PREFETCH=1 -DTRT_TRACE_MINWAVES=8 -shared -o $(OUT)/variants/libtrt_hip_pf_w8.so $(HIP_SRC)
 
 clean:
 	rm -rf $(OUT) tests/hostsim/libhostsim.so

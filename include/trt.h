@@ -157,7 +157,8 @@ enum {
     TRT_K_TRACE_CLOSEST = 1,
     TRT_K_SHADE = 2,
     TRT_K_TRACE_SHADOW = 3,
-    TRT_K_RESOLVE = 4
+    TRT_K_RESOLVE = 4,
+    TRT_K_TAIL = 5        /* the last, short-queue bounces of a pass fused into one launch */
 };
 
 typedef struct trt_stats {

@@ -24,6 +24,7 @@ struct HostScene {
     std::vector<MaterialDev> mats;
     std::vector<TextureDev> tex;
     std::vector<uint8_t> tex_bytes;
+    std::vector<float> cum;
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
     {
@@ -59,6 +60,15 @@ struct HostScene {
         sc.materials = mats.data();
         sc.lights = s->lights;
         sc.light_tris = s->light_tris;
+        bool mono = true;
+        for (uint32_t l = 0; l < s->n_lights; ++l)
+            for (uint32_t k = 0; k < s->lights[l].tri_count; ++k) {
+                const float c = s->light_tris[s->lights[l].tri_first + k].cum_area;
+                if (!(c == c) || (k && c < s->light_tris[s->lights[l].tri_first + k - 1].cum_area)) mono = false;
+            }
+        cum.resize(s->n_light_tris);
+        for (uint32_t k = 0; k < s->n_light_tris; ++k) cum[k] = s->light_tris[k].cum_area;
+        sc.light_cum = mono ? cum.data() : nullptr;
         sc.textures = tex.data();
         sc.tex_bytes = tex_bytes.data();
         sc.n_tris = s->n_tris;

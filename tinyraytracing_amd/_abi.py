@@ -15,7 +15,7 @@ TRT_INF = 114514.0
 TRT_FLAG_TIMING = 1
 TRT_FLAG_COUNT = 2
 TRT_MAX_KERNELS = 8
-KERNEL_NAMES = ["gen_primary", "trace_closest", "shade", "trace_shadow", "resolve"]
+KERNEL_NAMES = ["gen_primary", "trace_closest", "shade", "trace_shadow", "resolve", "tail"]
 
 c_float3 = C.c_float * 3
 
@@ -148,7 +148,7 @@ def load_hip():
     if _hip is not None:
         return _hip
     _bind_to_torch_hip_runtime()
-    path = os.path.join(LIB_DIR, "libtrt_hip.so")
+    path = os.environ.get("TRT_HIP_LIB") or os.path.join(LIB_DIR, "libtrt_hip.so")  # TRT_HIP_LIB: A/B tuning builds
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP extension is the only compute path; "
                            "build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make hip`")

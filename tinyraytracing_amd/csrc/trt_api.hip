@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -65,6 +66,7 @@ struct trt_handle {
     std::vector<void*> scene_allocs;
     std::vector<uint32_t> light_mats;
     uint32_t depth = 0;
+    uint32_t tail_n = 32768;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
     DevBuf arena, spill, small_buf, out_buf, io_buf;
     std::vector<hipEvent_t> events;
     ~trt_handle()
@@ -150,6 +152,13 @@ uint32_t traceGrid(uint32_t n)
     return (b + 7u) & ~7u;  // multiple of 8 for the XCD swizzle; <= MAX_TRACE_BLOCKS since that is one too
 }
 
+// Traversal stack variants: 8 or 16 LDS levels without spill code when the scene's verified BVH depth
+// fits, else the 16-level short stack with a global spill area (ordered traversal rarely goes that deep).
+template <bool COUNT>
+void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, const f4* rb, f4* hit, uint32_t n, DeviceStats* d_stats);
+template <bool COUNT>
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats);
+
 struct Timer {
     trt_handle* h;
     hipStream_t stream;
@@ -184,6 +193,26 @@ struct Timer {
         used++;
     }
 };
+
+template <bool COUNT>
+void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, const f4* rb, f4* hit, uint32_t n, DeviceStats* d_stats)
+{
+    uint32_t* spill = (uint32_t*)h->spill.p;
+    const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
+    if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+}
+
+template <bool COUNT>
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats)
+{
+    uint32_t* spill = (uint32_t*)h->spill.p;
+    const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
+    if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+}
 
 }  // namespace
 
@@ -235,6 +264,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     std::unique_ptr<trt_handle> h(new trt_handle);
     h->device = device;
     h->depth = depth;
+    if (const char* e = std::getenv("TRT_TAIL_N")) h->tail_n = (uint32_t)std::strtoul(e, nullptr, 10);
 
     {   // 48-B intersection records and 64-B shading records
         std::vector<TriIsect> isect(s->n_tris);
@@ -264,6 +294,19 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     }
     if (int e = upload(h.get(), s->lights, (size_t)s->n_lights, &h->sc.lights)) return e;
     if (int e = upload(h.get(), s->light_tris, (size_t)s->n_light_tris, &h->sc.light_tris)) return e;
+    {   // packed CDF for the bisection in lightSample; only when every light's CDF is non-decreasing and NaN-free
+        std::vector<float> cum(s->n_light_tris);
+        bool mono = true;
+        for (uint32_t k = 0; k < s->n_light_tris; ++k) cum[k] = s->light_tris[k].cum_area;
+        for (uint32_t l = 0; l < s->n_lights; ++l)
+            for (uint32_t k = 0; k < s->lights[l].tri_count; ++k) {
+                const float c = cum[s->lights[l].tri_first + k];
+                if (!(c == c) || (k && c < cum[s->lights[l].tri_first + k - 1])) mono = false;
+            }
+        h->sc.light_cum = nullptr;
+        if (mono)
+            if (int e = upload(h.get(), cum.data(), cum.size(), &h->sc.light_cum)) return e;
+    }
     {
         std::vector<TextureDev> tex(s->n_textures);
         std::vector<uint8_t> bytes;
@@ -285,7 +328,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     for (uint32_t i = 0; i < s->n_lights; ++i) h->light_mats.push_back((uint32_t)s->lights[i].mat);
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
-    const uint32_t spill_levels = depth > (uint32_t)TRT_LDS_STACK ? depth - TRT_LDS_STACK + 1 : 1;
+    const uint32_t spill_levels = depth > (uint32_t)TRT_LDS_STACK_MAX ? depth - TRT_LDS_STACK_MAX + 1 : 1;
     if (int e = h->spill.ensure((size_t)spill_levels * SPILL_STRIDE * sizeof(uint32_t))) return e;
     *out = h.release();
     return TRT_OK;
@@ -375,7 +418,6 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     if (!ev_begin || !ev_end) return fail(TRT_EHIP, "hipEventCreate failed");
     HIPC(hipEventRecord(ev_begin, stream));
 
-    uint32_t* spill = (uint32_t*)h->spill.p;
     std::vector<uint32_t> host_counts(2 * COUNT_ROW);
     uint32_t deepest = 0;
     for (uint32_t chunk = 0; chunk < n_chunks; ++chunk) {
@@ -393,8 +435,8 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         int cur = 0;
         for (uint32_t b = 0; n_active > 0 && b < MAX_BOUNCES; ++b) {
             tm.begin(TRT_K_TRACE_CLOSEST);
-            if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(traceGrid(n_active)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, Q[cur].ra, Q[cur].rb, hit, n_active, spill, SPILL_STRIDE, d_stats);
-            else hipLaunchKernelGGL(k_trace_closest<false>, dim3(traceGrid(n_active)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, Q[cur].ra, Q[cur].rb, hit, n_active, spill, SPILL_STRIDE, d_stats);
+            if (count) launchTraceClosest<true>(h, stream, Q[cur].ra, Q[cur].rb, hit, n_active, d_stats);
+            else launchTraceClosest<false>(h, stream, Q[cur].ra, Q[cur].rb, hit, n_active, d_stats);
             tm.end();
             st.launches[TRT_K_TRACE_CLOSEST]++;
 
@@ -424,8 +466,8 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
                 if (ns > n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");
                 if (!ns) continue;
                 tm.begin(TRT_K_TRACE_SHADOW);
-                if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(traceGrid(ns)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, SQ[l], ns, h->light_mats[l], Lacc, spill, SPILL_STRIDE, d_stats);
-                else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(traceGrid(ns)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, SQ[l], ns, h->light_mats[l], Lacc, spill, SPILL_STRIDE, d_stats);
+                if (count) launchTraceShadow<true>(h, stream, SQ[l], ns, h->light_mats[l], Lacc, d_stats);
+                else launchTraceShadow<false>(h, stream, SQ[l], ns, h->light_mats[l], Lacc, d_stats);
                 tm.end();
                 st.launches[TRT_K_TRACE_SHADOW]++;
                 st.rays_shadow += ns;
@@ -436,6 +478,25 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
             n_active = n_next;
             cur ^= 1;
             deepest = std::max(deepest, b);
+            if (n_active > 0 && n_active <= h->tail_n) {
+                // few paths left: finish them in one launch (k_tail) instead of ~3 launches + a sync per bounce
+                TailArgs TA;
+                TA.q = Q[cur];
+                TA.n = n_active;
+                TA.Lacc = Lacc;
+                TA.td = td;
+                TA.s0 = s0;
+                TA.max_depth = p->max_depth;
+                TA.spill = (uint32_t*)h->spill.p;
+                TA.spill_stride = SPILL_STRIDE;
+                TA.stats = d_stats;
+                tm.begin(TRT_K_TAIL);
+                if (count) hipLaunchKernelGGL(k_tail<true>, dim3(traceGrid(n_active)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, TA);
+                else hipLaunchKernelGGL(k_tail<false>, dim3(traceGrid(n_active)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, TA);
+                tm.end();
+                st.launches[TRT_K_TAIL]++;
+                n_active = 0;
+            }
         }
         tm.begin(TRT_K_RESOLVE);
         hipLaunchKernelGGL(k_resolve, dim3(std::min<uint32_t>((npix + 255) / 256, 65536u)), dim3(256), 0, stream, Lacc, d_acc, npix, sc_count, (float)p->spp);
@@ -459,6 +520,8 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         if (hipEventElapsedTime(&k_ms, h->events[sp.e0], h->events[sp.e1]) == hipSuccess) st.kernel_ms[sp.k] += k_ms;
     }
     st.shaded_hits = ds.shaded_hits;
+    st.rays_shadow += ds.tail_rays_shadow;
+    st.rays_indirect += ds.tail_rays_indirect;
     for (int i = 0; i < 2; ++i) { st.inner_visits[i] = ds.inner_visits[i]; st.tri_tests[i] = ds.tri_tests[i]; }
     st.max_bounces = ds.max_depth_hit;
     st.passes = n_chunks;
@@ -508,7 +571,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     HIPC(hipEventCreate(&e0));
     HIPC(hipEventCreate(&e1));
     HIPC(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(traceGrid(n32)), dim3(TRT_TRACE_BLOCK), 0, nullptr, h->sc, ra, rb, hit, n32, (uint32_t*)h->spill.p, SPILL_STRIDE, d_stats);
+    launchTraceClosest<true>(h, nullptr, ra, rb, hit, n32, d_stats);
     HIPC(hipEventRecord(e1, nullptr));
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());

@@ -16,7 +16,7 @@
 //
 // Traversal stack: per-lane stack of node references in LDS, laid out
 // [level][lane] so a wave's accesses hit 64 consecutive banks; levels beyond
-// TRT_LDS_STACK spill to a per-thread global area.
+// the kernel's LDS depth (8 or 16 levels; 16 + spill when the scene's BVH is deeper) spill to a per-thread global area.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,8 +24,19 @@
 
 namespace trtd {
 
+// Build-time tuning knobs (A/B variants are built by `make variants` and picked with TRT_HIP_LIB):
+//   TRT_TRACE_MINWAVES  second __launch_bounds__ argument of the traversal kernels (0 = leave it to the compiler)
+//   TRT_PREFETCH        (trt_path.h) fetch the next triangle record of a leaf while the current one is tested
+#ifndef TRT_TRACE_MINWAVES
+#define TRT_TRACE_MINWAVES 0
+#endif
+#if TRT_TRACE_MINWAVES > 0
+#define TRT_TRACE_BOUNDS __launch_bounds__(256, TRT_TRACE_MINWAVES)
+#else
+#define TRT_TRACE_BOUNDS __launch_bounds__(256)
+#endif
 constexpr int TRT_TRACE_BLOCK = 256;
-constexpr int TRT_LDS_STACK = 24;       // 24 levels x 256 lanes x 4 B = 24 KiB per block
+constexpr int TRT_LDS_STACK_MAX = 16;   // the short stack: 16 levels x 256 lanes x 4 B = 16 KiB per block; deeper levels spill
 constexpr int TRT_SHADE_BLOCK = 512;
 constexpr int TRT_MAX_LIGHTS = 8;
 
@@ -44,22 +55,31 @@ struct DeviceStats {
     unsigned long long inner_visits[2];
     unsigned long long tri_tests[2];
     unsigned long long shaded_hits;
+    unsigned long long tail_rays_shadow, tail_rays_indirect;  // rays traced inside k_tail
     unsigned int max_depth_hit;
     unsigned int pad;
 };
 
+// DEPTH levels live in LDS ([level][lane]: conflict-free, one ds_read/ds_write per access).  With
+// SPILL the levels beyond DEPTH, which only a BVH deeper than DEPTH can reach, go to a per-thread
+// global area; without it the host guarantees depth <= DEPTH.
+template <int DEPTH, bool SPILL>
 struct LdsStack {
     uint32_t* lds;    // &smem[threadIdx.x]
     uint32_t* spill;  // &spill[global thread id]
     uint32_t spill_stride;
     __device__ void push(int sp, uint32_t v)
     {
-        if (sp < TRT_LDS_STACK) lds[sp * TRT_TRACE_BLOCK] = v;
-        else spill[(size_t)(sp - TRT_LDS_STACK) * spill_stride] = v;
+        if (!SPILL || sp < DEPTH) lds[sp * TRT_TRACE_BLOCK] = v;
+        else spill[(size_t)(sp - DEPTH) * spill_stride] = v;
     }
     __device__ uint32_t pop(int sp) const
     {
-        return sp < TRT_LDS_STACK ? lds[sp * TRT_TRACE_BLOCK] : spill[(size_t)(sp - TRT_LDS_STACK) * spill_stride];
+        if (!SPILL) return lds[sp * TRT_TRACE_BLOCK];
+        uint32_t v = lds[(sp < DEPTH ? sp : DEPTH - 1) * TRT_TRACE_BLOCK];
+        asm volatile("" : "+v"(v));  // keep this a ds_read: without it the two address spaces merge into a flat load
+        if (sp >= DEPTH) v = spill[(size_t)(sp - DEPTH) * spill_stride];
+        return v;
     }
 };
 
@@ -103,12 +123,12 @@ __global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, R
 
 // ---------------------------------------------------------------- K2 ----
 // traverseBVH (bvh.cpp:146-245) for every queued ray.
-template <bool COUNT>
-__global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_closest(SceneDev sc, const f4* __restrict__ ra, const f4* __restrict__ rb, f4* __restrict__ hit, uint32_t n,
+template <bool COUNT, int DEPTH, bool SPILL>
+__global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, const f4* __restrict__ ra, const f4* __restrict__ rb, f4* __restrict__ hit, uint32_t n,
                                                                    uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
-    __shared__ uint32_t smem[TRT_LDS_STACK * TRT_TRACE_BLOCK];
-    LdsStack stk;
+    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
+    LdsStack<DEPTH, SPILL> stk;
     stk.lds = smem + threadIdx.x;
     stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
     stk.spill_stride = spill_stride;
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_closest(SceneDev sc, 
     const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
     for (uint32_t i = lb * TRT_TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
         const f4 a = ra[i], b = rb[i];
-        const Hit h = traceClosest<LdsStack, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
+        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
         hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
     }
     if (COUNT) {
@@ -134,12 +154,12 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_closest(SceneDev sc, 
 // its material is the light's (Q5); then L += w.  One launch per light, in
 // light order; each path has at most one ray per launch, so the read-modify-
 // write of Lacc needs no atomic and the sum order is fixed.
-template <bool COUNT>
-__global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
+template <bool COUNT, int DEPTH, bool SPILL>
+__global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                                   uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
-    __shared__ uint32_t smem[TRT_LDS_STACK * TRT_TRACE_BLOCK];
-    LdsStack stk;
+    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
+    LdsStack<DEPTH, SPILL> stk;
     stk.lds = smem + threadIdx.x;
     stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
     stk.spill_stride = spill_stride;
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_shadow(SceneDev sc, S
     const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
     for (uint32_t i = lb * TRT_TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
         const f4 a = sq.sa[i], b = sq.sb[i];
-        const Hit h = traceClosest<LdsStack, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
+        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
         if (h.tri >= 0 && (h.flags >> 8) == light_mat) {
             const f4 w = sq.sw[i];
             const uint32_t pid = f2u(b.z);
@@ -269,6 +289,79 @@ __global__ __launch_bounds__(TRT_SHADE_BLOCK) void k_shade(SceneDev sc, ShadeArg
         if (s_shaded) atomicAdd(&A.stats->shaded_hits, (unsigned long long)s_shaded);
         if (s_anyhit) atomicMax(&A.stats->max_depth_hit, bounce_depth);
     }
+}
+
+// ------------------------------------------------------------- tail ----
+// The geometric tail of a pass: once few paths are left (a small fraction of a
+// percent of the work, but dozens of bounces), every remaining path is finished
+// by one lane in ONE launch instead of three launches and a host round trip per
+// bounce.  Same device functions, same order of operations per path as the
+// wavefront kernels (trace, shadeBegin, per light: sample + shadow trace + add,
+// shadeNext), so the result is unchanged.
+struct TailArgs {
+    RayQueue q;
+    uint32_t n;
+    f4* Lacc;
+    TileDesc td;
+    uint32_t s0;
+    int32_t max_depth;
+    uint32_t* spill;
+    uint32_t spill_stride;
+    DeviceStats* stats;
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs A)
+{
+    __shared__ uint32_t smem[TRT_LDS_STACK_MAX * TRT_TRACE_BLOCK];
+    LdsStack<TRT_LDS_STACK_MAX, true> stk;
+    stk.lds = smem + threadIdx.x;
+    stk.spill = A.spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
+    stk.spill_stride = A.spill_stride;
+    uint32_t ni[2] = {0, 0}, nt[2] = {0, 0};
+    unsigned long long n_shadow = 0, n_indirect = 0, n_shaded = 0;
+    uint32_t deepest = 0;
+    bool any = false;
+    const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
+    for (uint32_t i = blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x; i < A.n; i += stride) {
+        f4 ra = A.q.ra[i], rb = A.q.rb[i], bt = A.q.bt[i];
+        const uint32_t pid = f2u(rb.z);
+        f4 L = A.Lacc[pid];
+        for (;;) {
+            const Hit h = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni[0], nt[0]);
+            ShadeCtx c;
+            shadeBegin(sc, A.td, A.s0, ra, rb, bt, mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v), c);
+            if (c.had_hit) { any = true; deepest = c.depth > deepest ? c.depth : deepest; }
+            if (c.add_L) { L.x = L.x + c.addL.x; L.y = L.y + c.addL.y; L.z = L.z + c.addL.z; }
+            if (c.shade_ok) n_shaded++;
+            for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                f3 wo, contrib;
+                if (!c.shade_ok || !lightSample(sc, c.vx, c.m, li, c.rng, wo, contrib)) continue;
+                const f3 w = c.beta * contrib;
+                n_shadow++;
+                const Hit sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1]);
+                if (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)sc.lights[li].mat) { L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z; }
+            }
+            f4 nra, nrb, nbt;
+            if (!shadeNext(c, A.max_depth, nra, nrb, nbt)) break;
+            ra = nra; rb = nrb; bt = nbt;
+            n_indirect++;
+        }
+        A.Lacc[pid] = L;
+    }
+    const unsigned long long s_sh = waveSum(n_shadow), s_in = waveSum(n_indirect), s_sd = waveSum(n_shaded);
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (COUNT) { c0 = waveSum(ni[0]); c1 = waveSum(nt[0]); c2 = waveSum(ni[1]); c3 = waveSum(nt[1]); }
+    if ((threadIdx.x & 63) == 0) {
+        if (s_sh) atomicAdd(&A.stats->tail_rays_shadow, s_sh);
+        if (s_in) atomicAdd(&A.stats->tail_rays_indirect, s_in);
+        if (s_sd) atomicAdd(&A.stats->shaded_hits, s_sd);
+        if (COUNT) {
+            atomicAdd(&A.stats->inner_visits[0], c0); atomicAdd(&A.stats->tri_tests[0], c1);
+            atomicAdd(&A.stats->inner_visits[1], c2); atomicAdd(&A.stats->tri_tests[1], c3);
+        }
+    }
+    if (any) atomicMax(&A.stats->max_depth_hit, deepest);
 }
 
 // ---------------------------------------------------------------- K6 ----

@@ -17,6 +17,10 @@
 #include "trt.h"
 #include "trt_prims.h"
 
+#ifndef TRT_PREFETCH
+#define TRT_PREFETCH 1
+#endif
+
 namespace trtd {
 
 // ------------------------------------------------------------------ types ----
@@ -87,6 +91,7 @@ struct SceneDev {
     const MaterialDev* materials;
     const trt_light* lights;
     const trt_light_tri* light_tris;
+    const float* light_cum;  // light_tris[k].cum_area packed (the CDF of pathTracing.cpp:40); null = scan the structs
     const TextureDev* textures;
     const uint8_t* tex_bytes;
     uint32_t n_tris, n_nodes, n_lights;
@@ -117,9 +122,12 @@ TRT_HD inline TriIsect makeTriIsect(const float* v9, int32_t mat, bool emissive)
 // ------------------------------------------------ interactTriangle (a6) ----
 // bvh.cpp:177-209 in Moller-Trumbore form: the parallel cut
 // |N.d| < 1e-5 is |det| < tol, t < 0.0005 misses, and "strictly inside"
-// (bvh.cpp:196-198) is u > 0, v > 0, u + v < 1.  The divisions are deferred
-// until the sign tests have passed.
-TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& u_out, float& v_out)
+// (bvh.cpp:196-198) is u > 0, v > 0, u + v < 1.  Evaluated without early
+// exits (every lane of a wave runs the same instructions; a miss is a mask),
+// with det made positive by flipping the signs of all four scalars.  Returns
+// true for a hit; t = tn/det is formed only then, and the barycentrics
+// u = un/det, v = vn/det are left to the caller (needed once per ray).
+TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& un_out, float& vn_out, float& det_out)
 {
     const float v0x = T.a.x, v0y = T.a.y, v0z = T.a.z;
     const float e1x = T.a.w, e1y = T.b.x, e1z = T.b.y;
@@ -127,22 +135,24 @@ TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& u
     const float px = fmaf(d.y, e2z, -(d.z * e2y));
     const float py = fmaf(d.z, e2x, -(d.x * e2z));
     const float pz = fmaf(d.x, e2y, -(d.y * e2x));
-    float det = fmaf(e1z, pz, fmaf(e1y, py, e1x * px));
-    if (fabsf(det) < T.c.y) return false;  // bvh.cpp:185
+    const float det_s = fmaf(e1z, pz, fmaf(e1y, py, e1x * px));
     const float tx = o.x - v0x, ty = o.y - v0y, tz = o.z - v0z;
-    float un = fmaf(tz, pz, fmaf(ty, py, tx * px));
+    const float un_s = fmaf(tz, pz, fmaf(ty, py, tx * px));
     const float qx = fmaf(ty, e1z, -(tz * e1y));
     const float qy = fmaf(tz, e1x, -(tx * e1z));
     const float qz = fmaf(tx, e1y, -(ty * e1x));
-    float vn = fmaf(d.z, qz, fmaf(d.y, qy, d.x * qx));
-    float tn = fmaf(e2z, qz, fmaf(e2y, qy, e2x * qx));
-    if (det < 0.0f) { det = -det; un = -un; vn = -vn; tn = -tn; }
-    if (!(un > 0.0f && vn > 0.0f && (un + vn) < det)) return false;  // strict: edge points miss
+    const float vn_s = fmaf(d.z, qz, fmaf(d.y, qy, d.x * qx));
+    const float tn_s = fmaf(e2z, qz, fmaf(e2y, qy, e2x * qx));
+    const uint32_t sgn = f2u(det_s) & 0x80000000u;  // exact negation of all four when det < 0
+    const float det = u2f(f2u(det_s) ^ sgn), un = u2f(f2u(un_s) ^ sgn), vn = u2f(f2u(vn_s) ^ sgn), tn = u2f(f2u(tn_s) ^ sgn);
+    const bool cand = !(det < T.c.y) && un > 0.0f && vn > 0.0f && (un + vn) < det;  // bvh.cpp:185,196-198
+    if (!cand) return false;
     const float t = tn / det;
     if (t < TRT_T_MIN) return false;  // bvh.cpp:189
     t_out = t;
-    u_out = un / det;
-    v_out = vn / det;
+    un_out = un;
+    vn_out = vn;
+    det_out = det;
     return true;
 }
 
@@ -179,21 +189,37 @@ TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     Hit best;
     best.t = TRT_INF; best.tri = -1; best.u = 0.f; best.v = 0.f; best.flags = 0u;
+    float best_det = 1.0f;  // best.u / best.v hold the numerators un, vn until the end
     int sp = 0;
     uint32_t cur = 0;  // nodes[0] is always an inner node
     for (;;) {
         if (cur & TRT_LEAF_BIT) {
             const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
-            float lt = TRT_INF, lu = 0.f, lv = 0.f;
+            float lt = TRT_INF, lun = 0.f, lvn = 0.f, ldet = 1.0f;
             int32_t li = -1;
             uint32_t lflags = 0u;
-            for (uint32_t i = first; i < first + count; ++i) {
-                const TriIsect T = sc.tri_isect[i];
-                if (COUNT) n_tri++;
-                float t, u, v;
-                if (!triTest(T, o, d, t, u, v)) continue;
-                const uint32_t fl = f2u(T.c.z);
-                if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lu = u; lv = v; lflags = fl; }
+            if (count) {
+#if TRT_PREFETCH
+                TriIsect T = sc.tri_isect[first];
+#endif
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t i = first + k;
+#if TRT_PREFETCH
+                    // fetch the next record of the leaf while this one is tested
+                    const TriIsect Tn = sc.tri_isect[k + 1 < count ? i + 1 : i];
+#else
+                    const TriIsect T = sc.tri_isect[i];
+#endif
+                    if (COUNT) n_tri++;
+                    float t, un, vn, det;
+                    if (triTest(T, o, d, t, un, vn, det)) {
+                        const uint32_t fl = f2u(T.c.z);
+                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lun = un; lvn = vn; ldet = det; lflags = fl; }
+                    }
+#if TRT_PREFETCH
+                    T = Tn;
+#endif
+                }
             }
             if (li >= 0) {
                 bool take = lt < best.t;
@@ -201,7 +227,7 @@ TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
                     const bool lem = (lflags & 1u) != 0, bem = (best.flags & 1u) != 0;
                     take = lem ? (!bem || li < best.tri) : (!bem && li > best.tri);
                 }
-                if (take) { best.t = lt; best.tri = li; best.u = lu; best.v = lv; best.flags = lflags; }
+                if (take) { best.t = lt; best.tri = li; best.u = lun; best.v = lvn; best_det = ldet; best.flags = lflags; }
             }
             if (sp == 0) break;
             cur = stk.pop(--sp);
@@ -229,6 +255,10 @@ TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
             if (sp == 0) break;
             cur = stk.pop(--sp);
         }
+    }
+    if (best.tri >= 0) {  // barycentric weights of v1, v2 (the values findBaryCor feeds bvh.cpp:224)
+        best.u = best.u / best_det;
+        best.v = best.v / best_det;
     }
     return best;
 }
@@ -360,9 +390,20 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
 {
     const trt_light L = sc.lights[li];
     const float rnd = rng.next() * sc.light0_area;  // Q3
+    // first triangle whose cumulative area exceeds rnd (the linear scan of pathTracing.cpp:38-42); on a
+    // non-decreasing CDF a bisection finds the same index
     const trt_light_tri* lt = nullptr;
-    for (uint32_t k = 0; k < L.tri_count; ++k)
-        if (rnd < sc.light_tris[L.tri_first + k].cum_area) { lt = &sc.light_tris[L.tri_first + k]; break; }
+    if (sc.light_cum) {
+        uint32_t lo = 0, hi = L.tri_count;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rnd < sc.light_cum[L.tri_first + mid]) hi = mid; else lo = mid + 1;
+        }
+        if (lo < L.tri_count) lt = &sc.light_tris[L.tri_first + lo];
+    } else {
+        for (uint32_t k = 0; k < L.tri_count; ++k)
+            if (rnd < sc.light_tris[L.tri_first + k].cum_area) { lt = &sc.light_tris[L.tri_first + k]; break; }
+    }
     if (!lt) return false;
     const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
     const float rs = (r1 + r2) + r3;
