@@ -168,6 +168,8 @@ typedef struct trt_stats {
     uint64_t shaded_hits;       /* path vertices that reached shade() */
     uint64_t inner_visits[2];   /* [closest, shadow] inner nodes whose two child boxes were tested (TRT_FLAG_COUNT) */
     uint64_t tri_tests[2];      /* [closest, shadow] triangle tests (TRT_FLAG_COUNT) */
+    uint64_t wave_steps[2];     /* wave-level iterations of the traversal kernels' [inner-node, leaf] phases (TRT_FLAG_COUNT):
+                                 * inner_visits / (64 * wave_steps[0]) is the SIMD utilisation of the inner phase */
     uint64_t launches[TRT_MAX_KERNELS];
     double kernel_ms[TRT_MAX_KERNELS]; /* summed launch durations (TRT_FLAG_TIMING) */
     double render_ms;           /* first gen_primary launch -> last resolve, device time */

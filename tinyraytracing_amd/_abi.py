@@ -67,7 +67,7 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays_camera", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_indirect", C.c_uint64),
-                ("shaded_hits", C.c_uint64), ("inner_visits", C.c_uint64 * 2), ("tri_tests", C.c_uint64 * 2),
+                ("shaded_hits", C.c_uint64), ("inner_visits", C.c_uint64 * 2), ("tri_tests", C.c_uint64 * 2), ("wave_steps", C.c_uint64 * 2),
                 ("launches", C.c_uint64 * TRT_MAX_KERNELS), ("kernel_ms", C.c_double * TRT_MAX_KERNELS),
                 ("render_ms", C.c_double), ("passes", C.c_uint32), ("max_bounces", C.c_uint32),
                 ("rows_rendered", C.c_uint64)]

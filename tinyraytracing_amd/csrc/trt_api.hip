@@ -152,8 +152,8 @@ uint32_t traceGrid(uint32_t n)
     return (b + 7u) & ~7u;  // multiple of 8 for the XCD swizzle; <= MAX_TRACE_BLOCKS since that is one too
 }
 
-// Traversal stack variants: 8 or 16 LDS levels without spill code when the scene's verified BVH depth
-// fits, else the 16-level short stack with a global spill area (ordered traversal rarely goes that deep).
+// Traversal stack variants: 8 / 16 / 24 / 32 LDS levels without spill code when the scene's verified
+// BVH depth fits (the smallest that does: more resident waves per CU), else 32 levels + a global spill area.
 template <bool COUNT>
 void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, const f4* rb, f4* hit, uint32_t n, DeviceStats* d_stats);
 template <bool COUNT>
@@ -201,6 +201,8 @@ void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, c
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
     else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    else if (h->depth <= 24) hipLaunchKernelGGL((k_trace_closest<COUNT, 24, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    else if (h->depth <= 32) hipLaunchKernelGGL((k_trace_closest<COUNT, 32, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
     else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
 }
 
@@ -211,6 +213,8 @@ void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueu
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
     else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    else if (h->depth <= 24) hipLaunchKernelGGL((k_trace_shadow<COUNT, 24, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    else if (h->depth <= 32) hipLaunchKernelGGL((k_trace_shadow<COUNT, 32, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
     else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
 }
 
@@ -520,6 +524,8 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         if (hipEventElapsedTime(&k_ms, h->events[sp.e0], h->events[sp.e1]) == hipSuccess) st.kernel_ms[sp.k] += k_ms;
     }
     st.shaded_hits = ds.shaded_hits;
+    st.wave_steps[0] = ds.wave_inner_steps;
+    st.wave_steps[1] = ds.wave_leaf_steps;
     st.rays_shadow += ds.tail_rays_shadow;
     st.rays_indirect += ds.tail_rays_indirect;
     for (int i = 0; i < 2; ++i) { st.inner_visits[i] = ds.inner_visits[i]; st.tri_tests[i] = ds.tri_tests[i]; }
@@ -592,6 +598,8 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
         std::memset(stats_out, 0, sizeof(*stats_out));
         stats_out->inner_visits[0] = ds.inner_visits[0];
         stats_out->tri_tests[0] = ds.tri_tests[0];
+        stats_out->wave_steps[0] = ds.wave_inner_steps;
+        stats_out->wave_steps[1] = ds.wave_leaf_steps;
         stats_out->kernel_ms[TRT_K_TRACE_CLOSEST] = ms;
         stats_out->launches[TRT_K_TRACE_CLOSEST] = 1;
     }

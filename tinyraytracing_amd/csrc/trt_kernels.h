@@ -16,7 +16,7 @@
 //
 // Traversal stack: per-lane stack of node references in LDS, laid out
 // [level][lane] so a wave's accesses hit 64 consecutive banks; levels beyond
-// the kernel's LDS depth (8 or 16 levels; 16 + spill when the scene's BVH is deeper) spill to a per-thread global area.
+// the kernel's LDS depth (8 / 16 / 24 / 32 levels; 32 + spill when the scene's BVH is deeper) spill to a per-thread global area.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -36,7 +36,7 @@ namespace trtd {
 #define TRT_TRACE_BOUNDS __launch_bounds__(256)
 #endif
 constexpr int TRT_TRACE_BLOCK = 256;
-constexpr int TRT_LDS_STACK_MAX = 16;   // the short stack: 16 levels x 256 lanes x 4 B = 16 KiB per block; deeper levels spill
+constexpr int TRT_LDS_STACK_MAX = 32;   // deepest LDS stack: 32 levels x 256 lanes x 4 B = 32 KiB per block; deeper levels spill
 constexpr int TRT_SHADE_BLOCK = 512;
 constexpr int TRT_MAX_LIGHTS = 8;
 
@@ -56,6 +56,7 @@ struct DeviceStats {
     unsigned long long tri_tests[2];
     unsigned long long shaded_hits;
     unsigned long long tail_rays_shadow, tail_rays_indirect;  // rays traced inside k_tail
+    unsigned long long wave_inner_steps, wave_leaf_steps;     // wave-level iterations of the two traversal phases (COUNT)
     unsigned int max_depth_hit;
     unsigned int pad;
 };
@@ -121,71 +122,188 @@ __global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, R
     }
 }
 
-// ---------------------------------------------------------------- K2 ----
-// traverseBVH (bvh.cpp:146-245) for every queued ray.
-template <bool COUNT, int DEPTH, bool SPILL>
-__global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, const f4* __restrict__ ra, const f4* __restrict__ rb, f4* __restrict__ hit, uint32_t n,
-                                                                   uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
+// ------------------------------------------------------------ K2 / K4 ----
+// traverseBVH (bvh.cpp:146-245) for every queued ray, as a persistent-wave
+// "while-while" traversal:
+//   * every wave owns a contiguous slice of the queue; lanes whose ray has
+//     finished are refilled from the slice (__ballot of idle lanes, rank by
+//     popcount of the lower lanes), so a wave does not idle behind its longest ray;
+//   * inner-node steps and leaf steps run in separate loops: lanes that have
+//     reached a leaf wait until no lane of the wave has an inner node left, then
+//     all pending leaves are intersected together.
+// Per ray the node/leaf visiting order, the culling rule and the tie rules are
+// exactly traceClosest()'s (trt_path.h), which the tail kernel, the ray-batch
+// tests' CPU twin (tests/hostsim) and this kernel therefore share.
+constexpr uint32_t TRT_REF_IDLE = 0xFFFFFFFFu;  // lane holds no ray (has the leaf bit set: never mistaken for an inner node)
+
+struct TraceProbe {  // COUNT builds only: work and SIMD utilisation of the two phases
+    uint32_t n_inner = 0, n_tri = 0;            // per lane: inner nodes visited, triangles tested
+    uint32_t wave_inner = 0, wave_tri = 0;      // counted by the first active lane: wave-level iterations
+};
+
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL>
+__device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+                                           const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
 {
-    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
     LdsStack<DEPTH, SPILL> stk;
     stk.lds = smem + threadIdx.x;
     stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
     stk.spill_stride = spill_stride;
-    uint32_t n_inner = 0, n_tri = 0;
-    const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
-    const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
-    for (uint32_t i = lb * TRT_TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
-        const f4 a = ra[i], b = rb[i];
-        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
-        hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    // contiguous queue slice of this wave (XCD-aware: neighbouring slices share an L2)
+    const uint32_t n_waves = gridDim.x * (TRT_TRACE_BLOCK / 64);
+    const uint32_t wave = xcdSwizzle(blockIdx.x, gridDim.x) * (TRT_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t per = (n + n_waves - 1) / n_waves;
+    const unsigned long long w0 = (unsigned long long)wave * per;
+    uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w0 < n ? w0 : n));
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)((w0 + per) < n ? (w0 + per) : n));
+
+    uint32_t cur = TRT_REF_IDLE, idx = 0, pid = 0;
+    int sp = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+    float best_t = TRT_INF;
+    int32_t best_tri = -1;
+    uint32_t best_flags = 0;
+    TraceProbe pr;
+
+    // ray finished: write its result, free the lane
+    auto finish = [&]() {
+        if (!SHADOW) {
+            // barycentric weights of v1, v2 (what findBaryCor feeds bvh.cpp:224): re-evaluated on the winning
+            // triangle once per ray instead of carrying three more registers through the traversal
+            float u = 0.f, v = 0.f;
+            if (best_tri >= 0) {
+                float t, un, vn, det;
+                if (triTest(sc.tri_isect[best_tri], o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
+            }
+            hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
+        } else if (best_tri >= 0 && (best_flags >> 8) == light_mat) {
+            // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material
+            const f4 w = sw[idx];
+            f4 L = Lacc[pid];
+            L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
+            Lacc[pid] = L;
+        }
+        cur = TRT_REF_IDLE;
+    };
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's slice
+        const unsigned long long idle = __ballot(cur == TRT_REF_IDLE);
+        if (idle != 0ull && next < end) {
+            const uint32_t rank = (uint32_t)__popcll(idle & lower);
+            if (cur == TRT_REF_IDLE && next + rank < end) {
+                idx = next + rank;
+                const f4 a = ra[idx], b = rb[idx];
+                o = mk3(a.x, a.y, a.z);
+                d = mk3(a.w, b.x, b.y);
+                if (SHADOW) pid = f2u(b.z);
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                best_t = TRT_INF; best_tri = -1; best_flags = 0u;
+                sp = 0;
+                cur = 0u;  // nodes[0] is always an inner node
+            }
+            const uint32_t taken = (uint32_t)__popcll(idle);
+            next = (end - next) < taken ? end : next + taken;
+        }
+        if (__ballot(cur != TRT_REF_IDLE) == 0ull) break;
+
+        // ---- inner-node phase: until no lane of the wave holds an inner node
+        for (;;) {
+            const bool is_inner = !(cur & TRT_LEAF_BIT);
+            const unsigned long long m = __ballot(is_inner);
+            if (m == 0ull) break;
+            if (is_inner) {
+                const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + cur);
+                const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
+                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
+                float e0, e1;
+                bool h0 = boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
+                bool h1 = boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
+                const uint32_t child0 = f2u(q3.x), child1 = f2u(q3.y);
+                h0 = h0 && !(e0 > best_t);  // skipped only when STRICTLY beyond the best hit: ties are still visited
+                h1 = h1 && !(e1 > best_t);
+                if (h0 && h1) {
+                    const bool swap = e1 < e0;
+                    stk.push(sp++, swap ? child0 : child1);
+                    cur = swap ? child1 : child0;
+                } else if (h0) {
+                    cur = child0;
+                } else if (h1) {
+                    cur = child1;
+                } else if (sp == 0) {
+                    finish();
+                } else {
+                    cur = stk.pop(--sp);
+                }
+            }
+        }
+
+        // ---- leaf phase: every active lane now holds a leaf (or waits idle)
+        for (;;) {
+            const bool is_leaf = cur != TRT_REF_IDLE && (cur & TRT_LEAF_BIT);
+            const unsigned long long m = __ballot(is_leaf);
+            if (m == 0ull) break;
+            if (is_leaf) {
+                const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
+                float lt = TRT_INF;
+                int32_t li = -1;
+                uint32_t lflags = 0u;
+                for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
+                    const uint32_t i = first + k;
+                    const TriIsect T = sc.tri_isect[i];
+                    if (COUNT) pr.n_tri++;
+                    float t, un, vn, det;
+                    if (triTest(T, o, d, t, un, vn, det)) {
+                        const uint32_t fl = f2u(T.c.z);
+                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lflags = fl; }
+                    }
+                }
+                if (li >= 0) {
+                    bool take = lt < best_t;
+                    if (lt == best_t && best_tri >= 0) {  // equal distance across leaves (bvh.cpp:168-172, order independent form)
+                        const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
+                        take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
+                    }
+                    if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
+                }
+                if (sp == 0) finish();
+                else cur = stk.pop(--sp);
+            }
+            if (COUNT && lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_tri++;
+        }
     }
     if (COUNT) {
-        const unsigned long long si = waveSum(n_inner), st = waveSum(n_tri);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats->inner_visits[0], si);
-            atomicAdd(&stats->tri_tests[0], st);
+        const unsigned long long si = waveSum(pr.n_inner), st = waveSum(pr.n_tri), wi = waveSum(pr.wave_inner), wt = waveSum(pr.wave_tri);
+        if (lane == 0) {
+            atomicAdd(&stats->inner_visits[SHADOW ? 1 : 0], si);
+            atomicAdd(&stats->tri_tests[SHADOW ? 1 : 0], st);
+            atomicAdd(&stats->wave_inner_steps, wi);
+            atomicAdd(&stats->wave_leaf_steps, wt);
         }
     }
 }
 
-// ---------------------------------------------------------------- K4 ----
+template <bool COUNT, int DEPTH, bool SPILL>
+__global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, const f4* __restrict__ ra, const f4* __restrict__ rb, f4* __restrict__ hit, uint32_t n,
+                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
+{
+    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
+    traceQueue<false, COUNT, DEPTH, SPILL>(sc, ra, rb, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem);
+}
+
 // Shadow test of shade() (pathTracing.cpp:51-58): CLOSEST hit, visible iff
 // its material is the light's (Q5); then L += w.  One launch per light, in
 // light order; each path has at most one ray per launch, so the read-modify-
 // write of Lacc needs no atomic and the sum order is fixed.
 template <bool COUNT, int DEPTH, bool SPILL>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
-                                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
+                                                uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
     __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
-    LdsStack<DEPTH, SPILL> stk;
-    stk.lds = smem + threadIdx.x;
-    stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
-    stk.spill_stride = spill_stride;
-    uint32_t n_inner = 0, n_tri = 0;
-    const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
-    const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
-    for (uint32_t i = lb * TRT_TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
-        const f4 a = sq.sa[i], b = sq.sb[i];
-        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
-        if (h.tri >= 0 && (h.flags >> 8) == light_mat) {
-            const f4 w = sq.sw[i];
-            const uint32_t pid = f2u(b.z);
-            f4 L = Lacc[pid];
-            L.x = L.x + w.x;
-            L.y = L.y + w.y;
-            L.z = L.z + w.z;
-            Lacc[pid] = L;
-        }
-    }
-    if (COUNT) {
-        const unsigned long long si = waveSum(n_inner), st = waveSum(n_tri);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats->inner_visits[1], si);
-            atomicAdd(&stats->tri_tests[1], st);
-        }
-    }
+    traceQueue<true, COUNT, DEPTH, SPILL>(sc, sq.sa, sq.sb, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem);
 }
 
 // Block-wide stream compaction slot: every thread calls it; threads with `flag`
