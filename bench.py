@@ -170,6 +170,11 @@ def main():
             "rays_rank0": {"camera": st.rays_camera, "shadow": st.rays_shadow, "indirect": st.rays_indirect},
             "device_render_ms_per_step_rank0": round(render_ms / a.steps, 3),
             "hbm_algorithmic_GBps_rank0": round(total_bytes_step * a.steps / (render_ms * 1e-3) / 1e9, 1) if render_ms > 0 else None,
+            "simd_utilisation_traversal": {
+                "inner_steps": round((st_count.inner_visits[0] + st_count.inner_visits[1]) / (64.0 * st_count.wave_steps[0]), 3) if st_count.wave_steps[0] else None,
+                "leaf_steps": round((st_count.tri_tests[0] + st_count.tri_tests[1]) / (64.0 * st_count.wave_steps[1]), 3) if st_count.wave_steps[1] else None,
+                "visits_per_ray": round((st_count.inner_visits[0] + st_count.inner_visits[1]) / max(st_count.rays, 1), 2),
+                "tri_tests_per_ray": round((st_count.tri_tests[0] + st_count.tri_tests[1]) / max(st_count.rays, 1), 2)},
             "roofline": roofline, "kernels_rank0": kernels, "passes": st.passes, "max_path_vertices": st.max_bounces + 1,
             "scene_load_build_s": round(t_load, 2),
         }

@@ -124,21 +124,24 @@ __global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, R
 
 // ------------------------------------------------------------ K2 / K4 ----
 // traverseBVH (bvh.cpp:146-245) for every queued ray, as a persistent-wave
-// "while-while" traversal:
+// traversal with a per-step wave scheduler:
 //   * every wave owns a contiguous slice of the queue; lanes whose ray has
-//     finished are refilled from the slice (__ballot of idle lanes, rank by
-//     popcount of the lower lanes), so a wave does not idle behind its longest ray;
-//   * inner-node steps and leaf steps run in separate loops: lanes that have
-//     reached a leaf wait until no lane of the wave has an inner node left, then
-//     all pending leaves are intersected together.
-// Per ray the node/leaf visiting order, the culling rule and the tie rules are
-// exactly traceClosest()'s (trt_path.h), which the tail kernel, the ray-batch
-// tests' CPU twin (tests/hostsim) and this kernel therefore share.
+//     finished are refilled from the slice (__ballot of idle lanes, rank =
+//     popcount of the lower idle lanes), so a wave never idles behind its
+//     longest ray;
+//   * a lane is either at an inner node (fetch 64 B, two slab tests, push/pop)
+//     or inside a leaf (one triangle test per step); each iteration the wave
+//     runs the step kind that more of its lanes are waiting for (two __ballot
+//     masks), so neither the box code nor the triangle code runs for a few
+//     stragglers while most lanes wait.
+// Per ray, the node/leaf visiting order, the culling rule and the tie rules are
+// exactly traceClosest()'s (trt_path.h), which the tail kernel and the tests'
+// CPU twin (tests/hostsim) use.
 constexpr uint32_t TRT_REF_IDLE = 0xFFFFFFFFu;  // lane holds no ray (has the leaf bit set: never mistaken for an inner node)
 
-struct TraceProbe {  // COUNT builds only: work and SIMD utilisation of the two phases
+struct TraceProbe {  // COUNT builds only: work and SIMD utilisation of the two step kinds
     uint32_t n_inner = 0, n_tri = 0;            // per lane: inner nodes visited, triangles tested
-    uint32_t wave_inner = 0, wave_tri = 0;      // counted by the first active lane: wave-level iterations
+    uint32_t wave_inner = 0, wave_tri = 0;      // counted by the first participating lane: wave-level steps
 };
 
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL>
@@ -166,28 +169,12 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
     float best_t = TRT_INF;
     int32_t best_tri = -1;
     uint32_t best_flags = 0;
+    // fold state of the leaf the lane is in (interactBVHNode's local `res`, bvh.cpp:213)
+    uint32_t lk = 0;  // next triangle of the leaf, relative to its first
+    float lt = TRT_INF;
+    int32_t li = -1;
+    uint32_t lflags = 0;
     TraceProbe pr;
-
-    // ray finished: write its result, free the lane
-    auto finish = [&]() {
-        if (!SHADOW) {
-            // barycentric weights of v1, v2 (what findBaryCor feeds bvh.cpp:224): re-evaluated on the winning
-            // triangle once per ray instead of carrying three more registers through the traversal
-            float u = 0.f, v = 0.f;
-            if (best_tri >= 0) {
-                float t, un, vn, det;
-                if (triTest(sc.tri_isect[best_tri], o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
-            }
-            hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
-        } else if (best_tri >= 0 && (best_flags >> 8) == light_mat) {
-            // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material
-            const f4 w = sw[idx];
-            f4 L = Lacc[pid];
-            L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
-            Lacc[pid] = L;
-        }
-        cur = TRT_REF_IDLE;
-    };
 
     for (;;) {
         // ---- refill idle lanes from the wave's slice
@@ -208,17 +195,18 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
             const uint32_t taken = (uint32_t)__popcll(idle);
             next = (end - next) < taken ? end : next + taken;
         }
-        if (__ballot(cur != TRT_REF_IDLE) == 0ull) break;
+        const bool is_inner = !(cur & TRT_LEAF_BIT);
+        const bool is_leaf = cur != TRT_REF_IDLE && (cur & TRT_LEAF_BIT);
+        const unsigned long long m_in = __ballot(is_inner), m_lf = __ballot(is_leaf);
+        if ((m_in | m_lf) == 0ull) break;  // every lane idle and the slice is exhausted
 
-        // ---- inner-node phase: until no lane of the wave holds an inner node
-        for (;;) {
-            const bool is_inner = !(cur & TRT_LEAF_BIT);
-            const unsigned long long m = __ballot(is_inner);
-            if (m == 0ull) break;
+        bool adv = false;  // this lane is done with its node: take the next one off the stack, or finish the ray
+        if (__popcll(m_in) >= __popcll(m_lf)) {
+            // ---- inner-node step
             if (is_inner) {
                 const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + cur);
                 const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
-                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
+                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
                 float e0, e1;
                 bool h0 = boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
                 bool h1 = boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
@@ -229,50 +217,66 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
                     const bool swap = e1 < e0;
                     stk.push(sp++, swap ? child0 : child1);
                     cur = swap ? child1 : child0;
-                } else if (h0) {
-                    cur = child0;
-                } else if (h1) {
-                    cur = child1;
-                } else if (sp == 0) {
-                    finish();
+                    lk = 0; lt = TRT_INF; li = -1;
+                } else if (h0 || h1) {
+                    cur = h0 ? child0 : child1;
+                    lk = 0; lt = TRT_INF; li = -1;
                 } else {
-                    cur = stk.pop(--sp);
+                    adv = true;
                 }
             }
-        }
-
-        // ---- leaf phase: every active lane now holds a leaf (or waits idle)
-        for (;;) {
-            const bool is_leaf = cur != TRT_REF_IDLE && (cur & TRT_LEAF_BIT);
-            const unsigned long long m = __ballot(is_leaf);
-            if (m == 0ull) break;
+        } else {
+            // ---- leaf step: one triangle of interactBVHNode's loop (bvh.cpp:211-229), index order
             if (is_leaf) {
                 const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
-                float lt = TRT_INF;
-                int32_t li = -1;
-                uint32_t lflags = 0u;
-                for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
-                    const uint32_t i = first + k;
+                if (lk < count) {
+                    const uint32_t i = first + lk;
                     const TriIsect T = sc.tri_isect[i];
-                    if (COUNT) pr.n_tri++;
+                    if (COUNT) { pr.n_tri++; if (lane == (uint32_t)__ffsll((long long)m_lf) - 1u) pr.wave_tri++; }
                     float t, un, vn, det;
                     if (triTest(T, o, d, t, un, vn, det)) {
                         const uint32_t fl = f2u(T.c.z);
                         if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lflags = fl; }
                     }
+                    lk++;
                 }
-                if (li >= 0) {
-                    bool take = lt < best_t;
-                    if (lt == best_t && best_tri >= 0) {  // equal distance across leaves (bvh.cpp:168-172, order independent form)
-                        const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
-                        take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
+                if (lk >= count) {  // leaf done: merge its winner, then the next node
+                    if (li >= 0) {
+                        bool take = lt < best_t;
+                        if (lt == best_t && best_tri >= 0) {  // equal distance across leaves (bvh.cpp:168-172, order independent form)
+                            const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
+                            take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
+                        }
+                        if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
                     }
-                    if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
+                    adv = true;
                 }
-                if (sp == 0) finish();
-                else cur = stk.pop(--sp);
             }
-            if (COUNT && lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_tri++;
+        }
+        if (adv) {
+            if (sp != 0) {
+                cur = stk.pop(--sp);
+                lk = 0; lt = TRT_INF; li = -1;
+            } else {
+                // ray finished: write its result, free the lane
+                if (!SHADOW) {
+                    // barycentric weights of v1, v2 (what findBaryCor feeds bvh.cpp:224): re-evaluated on the winning
+                    // triangle once per ray instead of carrying three more registers through the traversal
+                    float u = 0.f, v = 0.f;
+                    if (best_tri >= 0) {
+                        float t, un, vn, det;
+                        if (triTest(sc.tri_isect[best_tri], o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
+                    }
+                    hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
+                } else if (best_tri >= 0 && (best_flags >> 8) == light_mat) {
+                    // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material
+                    const f4 w = sw[idx];
+                    f4 L = Lacc[pid];
+                    L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
+                    Lacc[pid] = L;
+                }
+                cur = TRT_REF_IDLE;
+            }
         }
     }
     if (COUNT) {

@@ -8,5 +8,5 @@ line=sys.stdin.readline()
 if not line.strip(): print('%-34s FAILED' % '$label'); sys.exit(0)
 d=json.loads(line); k=d['kernels_rank0']
 g=lambda n: k.get(n,{}).get('ms_per_step',0.0)
-print('%-34s %9.1f Mrays/s %9.2f ms/step | closest %8.2f shadow %8.2f shade %8.2f tail %6.2f gen %5.2f | %s %.0f GB/s | rays %.3fG' % ('$label', d['value'], d['ms_per_step'], g('trace_closest'), g('trace_shadow'), g('shade'), g('tail'), g('gen_primary'), d['roofline']['kernel'], d['roofline']['achieved'], d['rays_per_step']/1e9))"
+print('%-34s %9.1f Mrays/s %9.2f ms/step | closest %8.2f shadow %8.2f shade %8.2f tail %6.2f gen %5.2f | %s %.0f GB/s | rays %.3fG | util %s' % ('$label', d['value'], d['ms_per_step'], g('trace_closest'), g('trace_shadow'), g('shade'), g('tail'), g('gen_primary'), d['roofline']['kernel'], d['roofline']['achieved'], d['rays_per_step']/1e9, d.get('simd_utilisation_traversal')))"
 done
