@@ -45,11 +45,16 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h 
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -Wl,-rpath,'$$ORIGIN'
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
+# name=defines, "+" separating the -D options
+VARIANTS := i1_l32=-DTRT_TRACE_IMPL=1+-DTRT_LDS_STACK_MAX_LEVELS=32 i1_l16=-DTRT_TRACE_IMPL=1+-DTRT_LDS_STACK_MAX_LEVELS=16 \
+            i2_l32=-DTRT_TRACE_IMPL=2+-DTRT_LDS_STACK_MAX_LEVELS=32 i2_l16=-DTRT_TRACE_IMPL=2+-DTRT_LDS_STACK_MAX_LEVELS=16 \
+            i3_l32=-DTRT_TRACE_IMPL=3+-DTRT_LDS_STACK_MAX_LEVELS=32 i3_l16=-DTRT_TRACE_IMPL=3+-DTRT_LDS_STACK_MAX_LEVELS=16 \
+            i2_l16_r1=-DTRT_TRACE_IMPL=2+-DTRT_LDS_STACK_MAX_LEVELS=16+-DTRT_REFILL_MIN=1 \
+            i2_l16_r32=-DTRT_TRACE_IMPL=2+-DTRT_LDS_STACK_MAX_LEVELS=16+-DTRT_REFILL_MIN=32
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
-	$(HIPCC) $(HIPFLAGS) -DTRT_PREFETCH=0 -shared -o $(OUT)/variants/libtrt_hip_nopf.so $(HIP_SRC)
-	$(HIPCC) $(HIPFLAGS) -DTRT_PREFETCH=0 -DTRT_TRACE_MINWAVES=8 -shared -o $(OUT)/variants/libtrt_hip_nopf_w8.so $(HIP_SRC)
-	$(HIPCC) $(HIPFLAGS) -DTRT_PREFETCH=1 -DTRT_TRACE_MINWAVES=8 -shared -o $(OUT)/variants/libtrt_hip_pf_w8.so $(HIP_SRC)
+	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \
+	  echo "variant $$name: $$defs"; $(HIPCC) $(HIPFLAGS) $$defs -shared -o $(OUT)/variants/libtrt_hip_$$name.so $(HIP_SRC) || exit 1; done
 
 clean:
 	rm -rf $(OUT) tests/hostsim/libhostsim.so

@@ -201,8 +201,10 @@ void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, c
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
     else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+#if TRT_LDS_STACK_MAX_LEVELS >= 32
     else if (h->depth <= 24) hipLaunchKernelGGL((k_trace_closest<COUNT, 24, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
     else if (h->depth <= 32) hipLaunchKernelGGL((k_trace_closest<COUNT, 32, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+#endif
     else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
 }
 
@@ -213,8 +215,10 @@ void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueu
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
     else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+#if TRT_LDS_STACK_MAX_LEVELS >= 32
     else if (h->depth <= 24) hipLaunchKernelGGL((k_trace_shadow<COUNT, 24, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
     else if (h->depth <= 32) hipLaunchKernelGGL((k_trace_shadow<COUNT, 32, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+#endif
     else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
 }
 

@@ -36,7 +36,10 @@ namespace trtd {
 #define TRT_TRACE_BOUNDS __launch_bounds__(256)
 #endif
 constexpr int TRT_TRACE_BLOCK = 256;
-constexpr int TRT_LDS_STACK_MAX = 32;   // deepest LDS stack: 32 levels x 256 lanes x 4 B = 32 KiB per block; deeper levels spill
+#ifndef TRT_LDS_STACK_MAX_LEVELS
+#define TRT_LDS_STACK_MAX_LEVELS 32
+#endif
+constexpr int TRT_LDS_STACK_MAX = TRT_LDS_STACK_MAX_LEVELS;   // deepest LDS stack (x 256 lanes x 4 B per block); deeper levels spill to global
 constexpr int TRT_SHADE_BLOCK = 512;
 constexpr int TRT_MAX_LIGHTS = 8;
 
@@ -123,27 +126,92 @@ __global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, R
 }
 
 // ------------------------------------------------------------ K2 / K4 ----
-// traverseBVH (bvh.cpp:146-245) for every queued ray, as a persistent-wave
-// traversal with a per-step wave scheduler:
-//   * every wave owns a contiguous slice of the queue; lanes whose ray has
-//     finished are refilled from the slice (__ballot of idle lanes, rank =
-//     popcount of the lower idle lanes), so a wave never idles behind its
-//     longest ray;
-//   * a lane is either at an inner node (fetch 64 B, two slab tests, push/pop)
-//     or inside a leaf (one triangle test per step); each iteration the wave
-//     runs the step kind that more of its lanes are waiting for (two __ballot
-//     masks), so neither the box code nor the triangle code runs for a few
-//     stragglers while most lanes wait.
-// Per ray, the node/leaf visiting order, the culling rule and the tie rules are
-// exactly traceClosest()'s (trt_path.h), which the tail kernel and the tests'
-// CPU twin (tests/hostsim) use.
-constexpr uint32_t TRT_REF_IDLE = 0xFFFFFFFFu;  // lane holds no ray (has the leaf bit set: never mistaken for an inner node)
+// traverseBVH (bvh.cpp:146-245) for every queued ray.  Per ray, the node/leaf
+// visiting order, the culling rule and the tie rules are exactly
+// traceClosest()'s (trt_path.h), whichever driver below runs it.
+//
+// TRT_TRACE_IMPL selects the wave-level driver (build-time; A/B variants via `make variants`):
+//   1  static: lane i takes rays i, i+stride, ...; a wave waits for its longest ray
+//   2  persistent wave, while-while: each wave owns a contiguous queue slice and refills finished
+//      lanes from it (__ballot of free lanes, rank = popcount of the lower free lanes); inner-node
+//      steps run until no lane holds an inner node, then all pending leaves are intersected
+//   3  persistent wave with a per-step scheduler: each iteration runs the step kind (inner node /
+//      one triangle) that more lanes are waiting for
+// TRT_REFILL_MIN (impl 2, 3): finished lanes are written back and refilled in batches of at least
+// this many lanes (ray set-up and result write-back then run at decent lane utilisation).
+#ifndef TRT_TRACE_IMPL
+#define TRT_TRACE_IMPL 1
+#endif
+#ifndef TRT_REFILL_MIN
+#define TRT_REFILL_MIN 16
+#endif
+
+constexpr uint32_t TRT_REF_IDLE = 0xFFFFFFFFu;  // lane holds no ray        } both have the leaf bit set and
+constexpr uint32_t TRT_REF_DONE = 0xFFFFFFFEu;  // ray finished, not stored } first >= 2^27 - 2: beyond TRT_MAX_TRIS, no builder emits them
 
 struct TraceProbe {  // COUNT builds only: work and SIMD utilisation of the two step kinds
     uint32_t n_inner = 0, n_tri = 0;            // per lane: inner nodes visited, triangles tested
     uint32_t wave_inner = 0, wave_tri = 0;      // counted by the first participating lane: wave-level steps
 };
 
+// result of one ray: hit record (closest) or the NEE accumulation (shadow)
+template <bool SHADOW>
+__device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, float best_t, int32_t best_tri, uint32_t best_flags, uint32_t idx, uint32_t pid,
+                                            f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc)
+{
+    if (!SHADOW) {
+        // barycentric weights of v1, v2 (what findBaryCor feeds bvh.cpp:224): re-evaluated on the winning
+        // triangle once per ray instead of carrying three more registers through the traversal
+        float u = 0.f, v = 0.f;
+        if (best_tri >= 0) {
+            float t, un, vn, det;
+            if (triTest(sc.tri_isect[best_tri], o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
+        }
+        hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
+    } else if (best_tri >= 0 && (best_flags >> 8) == light_mat) {
+        // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material
+        const f4 w = sw[idx];
+        f4 L = Lacc[pid];
+        L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
+        Lacc[pid] = L;
+    }
+}
+
+#if TRT_TRACE_IMPL == 1
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL>
+__device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+                                           const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
+{
+    LdsStack<DEPTH, SPILL> stk;
+    stk.lds = smem + threadIdx.x;
+    stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
+    stk.spill_stride = spill_stride;
+    uint32_t n_inner = 0, n_tri = 0;
+    const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
+    const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
+    for (uint32_t i = lb * TRT_TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
+        const f4 a = ra[i], b = rb[i];
+        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
+        if (!SHADOW) {
+            hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
+        } else if (h.tri >= 0 && (h.flags >> 8) == light_mat) {
+            const f4 w = sw[i];
+            const uint32_t pid = f2u(b.z);
+            f4 L = Lacc[pid];
+            L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
+            Lacc[pid] = L;
+        }
+    }
+    if (COUNT) {
+        const unsigned long long si = waveSum(n_inner), st = waveSum(n_tri);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&stats->inner_visits[SHADOW ? 1 : 0], si);
+            atomicAdd(&stats->tri_tests[SHADOW ? 1 : 0], st);
+        }
+    }
+}
+#else
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL>
 __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
@@ -169,37 +237,115 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
     float best_t = TRT_INF;
     int32_t best_tri = -1;
     uint32_t best_flags = 0;
+#if TRT_TRACE_IMPL == 3
     // fold state of the leaf the lane is in (interactBVHNode's local `res`, bvh.cpp:213)
     uint32_t lk = 0;  // next triangle of the leaf, relative to its first
     float lt = TRT_INF;
     int32_t li = -1;
     uint32_t lflags = 0;
+#endif
     TraceProbe pr;
 
     for (;;) {
-        // ---- refill idle lanes from the wave's slice
-        const unsigned long long idle = __ballot(cur == TRT_REF_IDLE);
-        if (idle != 0ull && next < end) {
-            const uint32_t rank = (uint32_t)__popcll(idle & lower);
-            if (cur == TRT_REF_IDLE && next + rank < end) {
-                idx = next + rank;
-                const f4 a = ra[idx], b = rb[idx];
-                o = mk3(a.x, a.y, a.z);
-                d = mk3(a.w, b.x, b.y);
-                if (SHADOW) pid = f2u(b.z);
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                best_t = TRT_INF; best_tri = -1; best_flags = 0u;
-                sp = 0;
-                cur = 0u;  // nodes[0] is always an inner node
+        // ---- write back finished rays and refill free lanes from the wave's slice, in batches
+        const bool working = cur < TRT_REF_DONE;
+        const unsigned long long m_work = __ballot(working);
+        const unsigned long long m_done = __ballot(cur == TRT_REF_DONE);
+        const unsigned long long m_free = ~m_work;  // finished or empty lanes
+        const bool can_fill = next < end;
+        if (m_work == 0ull || (m_done != 0ull && __popcll(can_fill ? m_free : m_done) >= TRT_REFILL_MIN)) {
+            if (cur == TRT_REF_DONE) {
+                storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc);
+                cur = TRT_REF_IDLE;
             }
-            const uint32_t taken = (uint32_t)__popcll(idle);
-            next = (end - next) < taken ? end : next + taken;
+            if (can_fill) {
+                const uint32_t rank = (uint32_t)__popcll(m_free & lower);
+                if (!working && next + rank < end) {
+                    idx = next + rank;
+                    const f4 a = ra[idx], b = rb[idx];
+                    o = mk3(a.x, a.y, a.z);
+                    d = mk3(a.w, b.x, b.y);
+                    if (SHADOW) pid = f2u(b.z);
+                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    best_t = TRT_INF; best_tri = -1; best_flags = 0u;
+                    sp = 0;
+                    cur = 0u;  // nodes[0] is always an inner node
+#if TRT_TRACE_IMPL == 3
+                    lk = 0; lt = TRT_INF; li = -1;
+#endif
+                }
+                const uint32_t taken = (uint32_t)__popcll(m_free);
+                next = (end - next) < taken ? end : next + taken;
+            }
+            if (__ballot(cur < TRT_REF_DONE) == 0ull) break;  // nothing left in the slice
         }
-        const bool is_inner = !(cur & TRT_LEAF_BIT);
-        const bool is_leaf = cur != TRT_REF_IDLE && (cur & TRT_LEAF_BIT);
-        const unsigned long long m_in = __ballot(is_inner), m_lf = __ballot(is_leaf);
-        if ((m_in | m_lf) == 0ull) break;  // every lane idle and the slice is exhausted
 
+#if TRT_TRACE_IMPL == 2
+        // ---- inner-node phase: until no lane of the wave holds an inner node
+        for (;;) {
+            const bool is_inner = !(cur & TRT_LEAF_BIT);
+            const unsigned long long m = __ballot(is_inner);
+            if (m == 0ull) break;
+            if (is_inner) {
+                const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + cur);
+                const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
+                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
+                float e0, e1;
+                bool h0 = boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
+                bool h1 = boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
+                const uint32_t child0 = f2u(q3.x), child1 = f2u(q3.y);
+                h0 = h0 && !(e0 > best_t);  // skipped only when STRICTLY beyond the best hit: ties are still visited
+                h1 = h1 && !(e1 > best_t);
+                if (h0 && h1) {
+                    const bool swap = e1 < e0;
+                    stk.push(sp++, swap ? child0 : child1);
+                    cur = swap ? child1 : child0;
+                } else if (h0 || h1) {
+                    cur = h0 ? child0 : child1;
+                } else if (sp == 0) {
+                    cur = TRT_REF_DONE;
+                } else {
+                    cur = stk.pop(--sp);
+                }
+            }
+        }
+        // ---- leaf phase: every working lane now holds a leaf
+        for (;;) {
+            const bool is_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
+            const unsigned long long m = __ballot(is_leaf);
+            if (m == 0ull) break;
+            if (is_leaf) {
+                const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
+                float lt = TRT_INF;
+                int32_t li = -1;
+                uint32_t lflags = 0u;
+                for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
+                    const uint32_t i = first + k;
+                    const TriIsect T = sc.tri_isect[i];
+                    if (COUNT) pr.n_tri++;
+                    float t, un, vn, det;
+                    if (triTest(T, o, d, t, un, vn, det)) {
+                        const uint32_t fl = f2u(T.c.z);
+                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lflags = fl; }
+                    }
+                }
+                if (li >= 0) {
+                    bool take = lt < best_t;
+                    if (lt == best_t && best_tri >= 0) {  // equal distance across leaves (bvh.cpp:168-172, order independent form)
+                        const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
+                        take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
+                    }
+                    if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
+                }
+                if (sp == 0) cur = TRT_REF_DONE;
+                else cur = stk.pop(--sp);
+            }
+            if (COUNT && lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_tri++;
+        }
+#else
+        const bool is_inner = !(cur & TRT_LEAF_BIT);
+        const bool is_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
+        const unsigned long long m_in = __ballot(is_inner), m_lf = __ballot(is_leaf);
         bool adv = false;  // this lane is done with its node: take the next one off the stack, or finish the ray
         if (__popcll(m_in) >= __popcll(m_lf)) {
             // ---- inner-node step
@@ -254,30 +400,11 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
             }
         }
         if (adv) {
-            if (sp != 0) {
-                cur = stk.pop(--sp);
-                lk = 0; lt = TRT_INF; li = -1;
-            } else {
-                // ray finished: write its result, free the lane
-                if (!SHADOW) {
-                    // barycentric weights of v1, v2 (what findBaryCor feeds bvh.cpp:224): re-evaluated on the winning
-                    // triangle once per ray instead of carrying three more registers through the traversal
-                    float u = 0.f, v = 0.f;
-                    if (best_tri >= 0) {
-                        float t, un, vn, det;
-                        if (triTest(sc.tri_isect[best_tri], o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
-                    }
-                    hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
-                } else if (best_tri >= 0 && (best_flags >> 8) == light_mat) {
-                    // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material
-                    const f4 w = sw[idx];
-                    f4 L = Lacc[pid];
-                    L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
-                    Lacc[pid] = L;
-                }
-                cur = TRT_REF_IDLE;
-            }
+            if (sp == 0) cur = TRT_REF_DONE;
+            else cur = stk.pop(--sp);
+            lk = 0; lt = TRT_INF; li = -1;
         }
+#endif
     }
     if (COUNT) {
         const unsigned long long si = waveSum(pr.n_inner), st = waveSum(pr.n_tri), wi = waveSum(pr.wave_inner), wt = waveSum(pr.wave_tri);
@@ -289,6 +416,7 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
         }
     }
 }
+#endif
 
 template <bool COUNT, int DEPTH, bool SPILL>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, const f4* __restrict__ ra, const f4* __restrict__ rb, f4* __restrict__ hit, uint32_t n,
