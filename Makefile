@@ -46,11 +46,7 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h 
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options
-VARIANTS := i1_l32=-DTRT_TRACE_IMPL=1+-DTRT_LDS_STACK_MAX_LEVELS=32 i1_l16=-DTRT_TRACE_IMPL=1+-DTRT_LDS_STACK_MAX_LEVELS=16 \
-            i2_l32=-DTRT_TRACE_IMPL=2+-DTRT_LDS_STACK_MAX_LEVELS=32 i2_l16=-DTRT_TRACE_IMPL=2+-DTRT_LDS_STACK_MAX_LEVELS=16 \
-            i3_l32=-DTRT_TRACE_IMPL=3+-DTRT_LDS_STACK_MAX_LEVELS=32 i3_l16=-DTRT_TRACE_IMPL=3+-DTRT_LDS_STACK_MAX_LEVELS=16 \
-            i2_l16_r1=-DTRT_TRACE_IMPL=2+-DTRT_LDS_STACK_MAX_LEVELS=16+-DTRT_REFILL_MIN=1 \
-            i2_l16_r32=-DTRT_TRACE_IMPL=2+-DTRT_LDS_STACK_MAX_LEVELS=16+-DTRT_REFILL_MIN=32
+VARIANTS := r8=-DTRT_REFILL_MIN=8 r32=-DTRT_REFILL_MIN=32 l32=-DTRT_LDS_STACK_MAX_LEVELS=32
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
 	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \

@@ -66,6 +66,7 @@ struct trt_handle {
     std::vector<void*> scene_allocs;
     std::vector<uint32_t> light_mats;
     uint32_t depth = 0;
+    int trace_impl = 3;       // wave driver of the traversal kernels (1 static, 2 while-while, 3 scheduler)
     uint32_t tail_n = 32768;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
     DevBuf arena, spill, small_buf, out_buf, io_buf;
     std::vector<hipEvent_t> events;
@@ -152,8 +153,9 @@ uint32_t traceGrid(uint32_t n)
     return (b + 7u) & ~7u;  // multiple of 8 for the XCD swizzle; <= MAX_TRACE_BLOCKS since that is one too
 }
 
-// Traversal stack variants: 8 / 16 / 24 / 32 LDS levels without spill code when the scene's verified
-// BVH depth fits (the smallest that does: more resident waves per CU), else 32 levels + a global spill area.
+// Traversal kernels: the LDS stack holds 8 or 16 levels without spill code when the scene's verified BVH
+// depth fits, else 16 levels + a global spill area (16 KiB per block keeps 8 waves per SIMD resident);
+// the wave driver (trt_kernels.h) is the static one for shallow trees, the scheduler one otherwise.
 template <bool COUNT>
 void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, const f4* rb, f4* hit, uint32_t n, DeviceStats* d_stats);
 template <bool COUNT>
@@ -199,13 +201,21 @@ void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, c
 {
     uint32_t* spill = (uint32_t*)h->spill.p;
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-    else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-#if TRT_LDS_STACK_MAX_LEVELS >= 32
-    else if (h->depth <= 24) hipLaunchKernelGGL((k_trace_closest<COUNT, 24, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-    else if (h->depth <= 32) hipLaunchKernelGGL((k_trace_closest<COUNT, 32, false>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-#endif
-    else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    if (h->trace_impl == 1) {
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    }
+    else if (h->trace_impl == 2) {
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 2>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 2>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 2>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    }
+    else if (h->trace_impl == 3) {
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 3>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 3>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 3>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    }
 }
 
 template <bool COUNT>
@@ -213,13 +223,21 @@ void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueu
 {
     uint32_t* spill = (uint32_t*)h->spill.p;
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-    else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-#if TRT_LDS_STACK_MAX_LEVELS >= 32
-    else if (h->depth <= 24) hipLaunchKernelGGL((k_trace_shadow<COUNT, 24, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-    else if (h->depth <= 32) hipLaunchKernelGGL((k_trace_shadow<COUNT, 32, false>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-#endif
-    else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    if (h->trace_impl == 1) {
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    }
+    else if (h->trace_impl == 2) {
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    }
+    else if (h->trace_impl == 3) {
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    }
 }
 
 }  // namespace
@@ -273,6 +291,10 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     h->device = device;
     h->depth = depth;
     if (const char* e = std::getenv("TRT_TAIL_N")) h->tail_n = (uint32_t)std::strtoul(e, nullptr, 10);
+    // shallow trees (everything L1-resident, a dozen steps per ray): the static driver has the least overhead;
+    // deeper ones gain more from lane refill and step scheduling (measured: DESIGN.md)
+    h->trace_impl = depth <= 8 ? 1 : 3;
+    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) h->trace_impl = v; }
 
     {   // 48-B intersection records and 64-B shading records
         std::vector<TriIsect> isect(s->n_tris);

@@ -37,7 +37,7 @@ namespace trtd {
 #endif
 constexpr int TRT_TRACE_BLOCK = 256;
 #ifndef TRT_LDS_STACK_MAX_LEVELS
-#define TRT_LDS_STACK_MAX_LEVELS 32
+#define TRT_LDS_STACK_MAX_LEVELS 16
 #endif
 constexpr int TRT_LDS_STACK_MAX = TRT_LDS_STACK_MAX_LEVELS;   // deepest LDS stack (x 256 lanes x 4 B per block); deeper levels spill to global
 constexpr int TRT_SHADE_BLOCK = 512;
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, R
 // visiting order, the culling rule and the tie rules are exactly
 // traceClosest()'s (trt_path.h), whichever driver below runs it.
 //
-// TRT_TRACE_IMPL selects the wave-level driver (build-time; A/B variants via `make variants`):
+// IMPL selects the wave-level driver (run time: trt_create picks it from the BVH depth, TRT_TRACE_IMPL
+// in the environment overrides):
 //   1  static: lane i takes rays i, i+stride, ...; a wave waits for its longest ray
 //   2  persistent wave, while-while: each wave owns a contiguous queue slice and refills finished
 //      lanes from it (__ballot of free lanes, rank = popcount of the lower free lanes); inner-node
@@ -139,9 +140,6 @@ __global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, R
 //      one triangle) that more lanes are waiting for
 // TRT_REFILL_MIN (impl 2, 3): finished lanes are written back and refilled in batches of at least
 // this many lanes (ray set-up and result write-back then run at decent lane utilisation).
-#ifndef TRT_TRACE_IMPL
-#define TRT_TRACE_IMPL 1
-#endif
 #ifndef TRT_REFILL_MIN
 #define TRT_REFILL_MIN 16
 #endif
@@ -177,9 +175,8 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
     }
 }
 
-#if TRT_TRACE_IMPL == 1
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL>
-__device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+__device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
 {
@@ -211,9 +208,8 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
         }
     }
 }
-#else
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL>
-__device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL>
+__device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
 {
@@ -237,13 +233,11 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
     float best_t = TRT_INF;
     int32_t best_tri = -1;
     uint32_t best_flags = 0;
-#if TRT_TRACE_IMPL == 3
-    // fold state of the leaf the lane is in (interactBVHNode's local `res`, bvh.cpp:213)
+    // IMPL 3: fold state of the leaf the lane is in (interactBVHNode's local `res`, bvh.cpp:213)
     uint32_t lk = 0;  // next triangle of the leaf, relative to its first
     float lt = TRT_INF;
     int32_t li = -1;
     uint32_t lflags = 0;
-#endif
     TraceProbe pr;
 
     for (;;) {
@@ -270,9 +264,7 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
                     best_t = TRT_INF; best_tri = -1; best_flags = 0u;
                     sp = 0;
                     cur = 0u;  // nodes[0] is always an inner node
-#if TRT_TRACE_IMPL == 3
                     lk = 0; lt = TRT_INF; li = -1;
-#endif
                 }
                 const uint32_t taken = (uint32_t)__popcll(m_free);
                 next = (end - next) < taken ? end : next + taken;
@@ -280,7 +272,7 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
             if (__ballot(cur < TRT_REF_DONE) == 0ull) break;  // nothing left in the slice
         }
 
-#if TRT_TRACE_IMPL == 2
+        if constexpr (IMPL == 2) {
         // ---- inner-node phase: until no lane of the wave holds an inner node
         for (;;) {
             const bool is_inner = !(cur & TRT_LEAF_BIT);
@@ -316,9 +308,9 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
             if (m == 0ull) break;
             if (is_leaf) {
                 const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
-                float lt = TRT_INF;
-                int32_t li = -1;
-                uint32_t lflags = 0u;
+                lt = TRT_INF;
+                li = -1;
+                lflags = 0u;
                 for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
                     const uint32_t i = first + k;
                     const TriIsect T = sc.tri_isect[i];
@@ -342,7 +334,7 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
             }
             if (COUNT && lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_tri++;
         }
-#else
+        } else {
         const bool is_inner = !(cur & TRT_LEAF_BIT);
         const bool is_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
         const unsigned long long m_in = __ballot(is_inner), m_lf = __ballot(is_leaf);
@@ -404,7 +396,7 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
             else cur = stk.pop(--sp);
             lk = 0; lt = TRT_INF; li = -1;
         }
-#endif
+        }
     }
     if (COUNT) {
         const unsigned long long si = waveSum(pr.n_inner), st = waveSum(pr.n_tri), wi = waveSum(pr.wave_inner), wt = waveSum(pr.wave_tri);
@@ -416,26 +408,34 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
         }
     }
 }
-#endif
 
-template <bool COUNT, int DEPTH, bool SPILL>
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL>
+__device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+                                           const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
+{
+    if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL>(sc, ra, rb, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL>(sc, ra, rb, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+}
+
+template <bool COUNT, int DEPTH, bool SPILL, int IMPL>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, const f4* __restrict__ ra, const f4* __restrict__ rb, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
     __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
-    traceQueue<false, COUNT, DEPTH, SPILL>(sc, ra, rb, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem);
+    traceQueue<false, COUNT, DEPTH, SPILL, IMPL>(sc, ra, rb, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem);
 }
 
 // Shadow test of shade() (pathTracing.cpp:51-58): CLOSEST hit, visible iff
 // its material is the light's (Q5); then L += w.  One launch per light, in
 // light order; each path has at most one ray per launch, so the read-modify-
 // write of Lacc needs no atomic and the sum order is fixed.
-template <bool COUNT, int DEPTH, bool SPILL>
+template <bool COUNT, int DEPTH, bool SPILL, int IMPL>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
     __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
-    traceQueue<true, COUNT, DEPTH, SPILL>(sc, sq.sa, sq.sb, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+    traceQueue<true, COUNT, DEPTH, SPILL, IMPL>(sc, sq.sa, sq.sb, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem);
 }
 
 // Block-wide stream compaction slot: every thread calls it; threads with `flag`
