@@ -149,8 +149,12 @@ def main():
         dom_bytes_step = by.get(dom_name, 0)
         dom_ms = kernel_ms[dom]
         achieved = dom_bytes_step * a.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None  # measured HBM bytes per launch of that kernel (PMC passes, committed under profiles/), when this is that workload
+        tpath = os.path.join(ROOT, "profiles", f"hbm_traffic_{a.scene}_{a.height}p_{a.spp}spp.json")
+        if world == 1 and a.width * 9 == a.height * 16 and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["bytes_per_launch"].get(dom_name)
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches_per_step": launches[dom] // max(a.steps, 1),
                     "avg_launch_ms": round(dom_ms / max(launches[dom], 1), 5),
                     "algorithmic_bytes_per_launch": int(dom_bytes_step * a.steps / max(launches[dom], 1)),
