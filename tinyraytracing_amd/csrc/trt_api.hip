@@ -66,7 +66,7 @@ struct trt_handle {
     std::vector<void*> scene_allocs;
     std::vector<uint32_t> light_mats;
     uint32_t depth = 0;
-    int trace_impl = 3;       // wave driver of the traversal kernels (1 static, 2 while-while, 3 scheduler)
+    int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
     uint32_t tail_n = 32768;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
     DevBuf arena, spill, small_buf, out_buf, io_buf;
     std::vector<hipEvent_t> events;
@@ -201,7 +201,8 @@ void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, c
 {
     uint32_t* spill = (uint32_t*)h->spill.p;
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->trace_impl == 1) {
+    if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_closest<COUNT, 1, false, 0>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    else if (h->trace_impl == 1) {
         if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
         else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
         else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
@@ -223,7 +224,8 @@ void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueu
 {
     uint32_t* spill = (uint32_t*)h->spill.p;
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->trace_impl == 1) {
+    if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_shadow<COUNT, 1, false, 0>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    else if (h->trace_impl == 1) {
         if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
         else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
         else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
@@ -293,8 +295,9 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     if (const char* e = std::getenv("TRT_TAIL_N")) h->tail_n = (uint32_t)std::strtoul(e, nullptr, 10);
     // shallow trees (everything L1-resident, a dozen steps per ray): the static driver has the least overhead;
     // deeper ones gain more from lane refill and step scheduling (measured: DESIGN.md)
-    h->trace_impl = depth <= 8 ? 1 : 3;
-    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) h->trace_impl = v; }
+    const bool tiny = s->n_nodes <= 32 && s->n_tris <= 64;  // the wave-uniform walk needs a 32-bit reach mask
+    h->trace_impl = tiny ? 0 : (depth <= 8 ? 1 : 3);
+    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { const int v = std::atoi(e); if (v >= (tiny ? 0 : 1) && v <= 3) h->trace_impl = v; }
 
     {   // 48-B intersection records and 64-B shading records
         std::vector<TriIsect> isect(s->n_tris);

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, R
 //
 // IMPL selects the wave-level driver (run time: trt_create picks it from the BVH depth, TRT_TRACE_IMPL
 // in the environment overrides):
+//   0  wave-uniform walk of a tiny tree (<= 32 inner nodes, <= 64 triangles): scalar loads, no stack
 //   1  static: lane i takes rays i, i+stride, ...; a wave waits for its longest ray
 //   2  persistent wave, while-while: each wave owns a contiguous queue slice and refills finished
 //      lanes from it (__ballot of free lanes, rank = popcount of the lower free lanes); inner-node
@@ -172,6 +173,86 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
         f4 L = Lacc[pid];
         L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
         Lacc[pid] = L;
+    }
+}
+
+// IMPL 0 — wave-uniform evaluation of a tiny BVH (<= 32 inner nodes): no stack, no divergent control
+// flow, no per-lane addresses.  The tree is walked in node-index order (the builders emit parents
+// before children) by the whole wave at once; a per-lane bit mask records which inner nodes the lane's
+// ray reaches (parent reached AND child box hit, bvh.cpp:162-166), node and triangle records are
+// fetched at wave-uniform addresses (scalar loads), and a leaf is intersected when any lane reaches it.
+// This is the reference's own visit set — both children, no culling by the best hit (bvh.cpp:146-175) —
+// so the counters equal the oracle's, and the result is the same as the ordered traversal's because
+// the leaf rule and the between-leaves rule are applied unchanged.
+template <bool SHADOW, bool COUNT>
+__device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+                                                  const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, DeviceStats* stats)
+{
+    uint32_t n_inner = 0, n_tri = 0;
+    const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
+    const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
+    const uint32_t n_nodes = sc.n_nodes;
+    for (uint32_t base = lb * TRT_TRACE_BLOCK; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t ii = valid ? i : n - 1;
+        const f4 a = ra[ii], b = rb[ii];
+        const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        uint32_t reach = valid ? 1u : 0u;  // bit k: the ray reaches inner node k
+        float best_t = TRT_INF;
+        int32_t best_tri = -1;
+        uint32_t best_flags = 0u;
+        for (uint32_t ni = 0; ni < n_nodes; ++ni) {
+            const bool at = (reach >> ni) & 1u;
+            if (__ballot(at) == 0ull) continue;
+            const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + ni);  // wave-uniform address
+            const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
+            if (COUNT && at) n_inner++;
+            float e0, e1;
+            const bool h0 = at && boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
+            const bool h1 = at && boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
+            const uint32_t child[2] = {f2u(q3.x), f2u(q3.y)};
+            const bool hc[2] = {h0, h1};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t ref = child[c];
+                if (!(ref & TRT_LEAF_BIT)) {
+                    reach |= hc[c] ? (1u << ref) : 0u;
+                    continue;
+                }
+                if (__ballot(hc[c]) == 0ull) continue;
+                const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
+                float lt = TRT_INF;  // interactBVHNode (bvh.cpp:211-229): index order, local fold
+                int32_t li = -1;
+                uint32_t lflags = 0u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const TriIsect T = sc.tri_isect[first + k];  // wave-uniform address
+                    if (COUNT && hc[c]) n_tri++;
+                    float t, un, vn, det;
+                    if (triTest(T, o, d, t, un, vn, det) && hc[c]) {
+                        const uint32_t fl = f2u(T.c.z);
+                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)(first + k); lflags = fl; }
+                    }
+                }
+                if (li >= 0) {
+                    bool take = lt < best_t;
+                    if (lt == best_t && best_tri >= 0) {  // equal distance across leaves (bvh.cpp:168-172, order independent form)
+                        const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
+                        take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
+                    }
+                    if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
+                }
+            }
+        }
+        if (valid) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc);
+    }
+    if (COUNT) {
+        const unsigned long long si = waveSum(n_inner), st = waveSum(n_tri);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&stats->inner_visits[SHADOW ? 1 : 0], si);
+            atomicAdd(&stats->tri_tests[SHADOW ? 1 : 0], st);
+        }
     }
 }
 
@@ -414,7 +495,8 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restr
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
 {
-    if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL>(sc, ra, rb, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+    if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT>(sc, ra, rb, n, hit, sw, light_mat, Lacc, stats);
+    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL>(sc, ra, rb, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
     else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL>(sc, ra, rb, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
 }
 
