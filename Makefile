@@ -46,7 +46,7 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h 
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options
-VARIANTS := r8=-DTRT_REFILL_MIN=8 r32=-DTRT_REFILL_MIN=32 l32=-DTRT_LDS_STACK_MAX_LEVELS=32
+VARIANTS := sb256=-DTRT_SHADE_BLOCK_THREADS=256 sb1024=-DTRT_SHADE_BLOCK_THREADS=1024
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
 	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \

@@ -45,12 +45,13 @@ def test_trace_matches_oracle_on_incoherent_rays(name, n, renderer_factory):
     s = get_scene(name, 64, 36)
     lo, hi = raygen.scene_bounds(s)
     org, dirs = raygen.random_rays(n, lo - 5, hi + 5, seed=99)
-    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    t0, tri0, uv0, ost = O.trace(s.flat, org, dirs, want_stats=True)
     t1, tri1, uv1, st = renderer_factory(s).trace_closest(org, dirs, want_stats=True)
     assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
-    # the kernel runs the same traversal as the hostsim: identical visit counts
+    # visit counts: the ordered/culled drivers run traceClosest() like the hostsim; the wave-uniform
+    # tiny-tree driver visits the reference's unculled set like the oracle
     _, _, _, cnt = H.trace(s.flat, org, dirs)
-    assert [st.inner_visits[0], st.tri_tests[0]] == cnt
+    assert [st.inner_visits[0], st.tri_tests[0]] in (cnt, [ost.inner_visits[0], ost.tri_tests[0]])
 
 
 def test_trace_soup_deep_bvh(renderer_factory):

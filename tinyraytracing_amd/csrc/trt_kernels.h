@@ -40,7 +40,10 @@ constexpr int TRT_TRACE_BLOCK = 256;
 #define TRT_LDS_STACK_MAX_LEVELS 16
 #endif
 constexpr int TRT_LDS_STACK_MAX = TRT_LDS_STACK_MAX_LEVELS;   // deepest LDS stack (x 256 lanes x 4 B per block); deeper levels spill to global
-constexpr int TRT_SHADE_BLOCK = 512;
+#ifndef TRT_SHADE_BLOCK_THREADS
+#define TRT_SHADE_BLOCK_THREADS 512
+#endif
+constexpr int TRT_SHADE_BLOCK = TRT_SHADE_BLOCK_THREADS;
 constexpr int TRT_MAX_LIGHTS = 8;
 
 struct RayQueue {
