@@ -1,9 +1,12 @@
 #!/bin/bash
-# variants x workloads matrix on the GPU box; prints one line per run as it goes.
+# variants x workloads on the GPU box.  usage: tools/matrix.sh "<variant names>" ["label|bench args" ...]
+# a variant name "default" means the in-tree libtrt_hip.so
 V=tinyraytracing_amd/lib/variants
-for name in "$@"; do
-  lib=$V/libtrt_hip_$name.so
-  ok=$(TRT_HIP_LIB=$lib timeout -k 10 200 python -m pytest tests/test_gpu_parity.py -x -q -k "golden or incoherent or soup_deep" 2>&1 | tail -1)
-  echo "## $name parity: $ok"
-  tools/ab.sh "$name back|TRT_HIP_LIB=$lib|--steps 2" "$name veach l4|TRT_HIP_LIB=$lib|--scene veach-mis --steps 1 --leaf 4" "$name stair l4|TRT_HIP_LIB=$lib|--scene staircase --spp 64 --steps 1 --leaf 4" "$name soup l4|TRT_HIP_LIB=$lib|--scene soup --spp 16 --steps 1 --leaf 4"
+names=$1; shift
+if [ $# -eq 0 ]; then set -- "back|--steps 3" "veach|--scene veach-mis --steps 2" "stair64|--scene staircase --spp 64 --steps 1" "soup16|--scene soup --spp 16 --steps 1"; fi
+for name in $names; do
+  if [ "$name" = default ]; then lib=tinyraytracing_amd/lib/libtrt_hip.so; else lib=$V/libtrt_hip_$name.so; fi
+  for w in "$@"; do
+    tools/ab.sh "$name ${w%%|*}|TRT_HIP_LIB=$lib|${w#*|}"
+  done
 done
