@@ -46,7 +46,7 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h 
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options
-VARIANTS := s1=-DTRT_SHADE_SLOTS=1 s2=-DTRT_SHADE_SLOTS=2 s3=-DTRT_SHADE_SLOTS=3 s2w4=-DTRT_SHADE_SLOTS=2+-DTRT_SHADE_MINWAVES=4 s3w4=-DTRT_SHADE_SLOTS=3+-DTRT_SHADE_MINWAVES=4 s1w6=-DTRT_SHADE_SLOTS=1+-DTRT_SHADE_MINWAVES=6
+VARIANTS := sw5=-DTRT_SHADE_MINWAVES=5
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
 	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \

@@ -25,6 +25,8 @@ struct HostScene {
     std::vector<TextureDev> tex;
     std::vector<uint8_t> tex_bytes;
     std::vector<float> cum;
+    std::vector<LightDev> lights;
+    std::vector<LightTriDev> ltris;
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
     {
@@ -38,14 +40,11 @@ struct HostScene {
             shade[i].mat = mat;
         }
         mats.resize(s->n_materials);
-        for (uint32_t i = 0; i < s->n_materials; ++i) {
-            const trt_material& m = s->materials[i];
-            MaterialDev& d = mats[i];
-            std::memcpy(d.Kd, m.Kd, 12); std::memcpy(d.Ks, m.Ks, 12); std::memcpy(d.Tr, m.Tr, 12);
-            d.Ns = m.Ns; d.Ni = m.Ni;
-            std::memcpy(d.radiance, m.radiance, 12);
-            d.is_emissive = m.is_emissive; d.tex = m.tex;
-        }
+        for (uint32_t i = 0; i < s->n_materials; ++i) mats[i] = makeMaterialDev(s->materials[i]);
+        lights.resize(s->n_lights);
+        for (uint32_t i = 0; i < s->n_lights; ++i) lights[i] = makeLightDev(s->lights[i]);
+        ltris.resize(s->n_light_tris);
+        for (uint32_t i = 0; i < s->n_light_tris; ++i) ltris[i] = makeLightTriDev(s->light_tris[i]);
         tex.resize(s->n_textures);
         for (uint32_t i = 0; i < s->n_textures; ++i) {
             tex[i].width = s->textures[i].width;
@@ -58,8 +57,8 @@ struct HostScene {
         sc.tri_isect = isect.data();
         sc.tri_shade = shade.data();
         sc.materials = mats.data();
-        sc.lights = s->lights;
-        sc.light_tris = s->light_tris;
+        sc.lights = lights.data();
+        sc.light_tris = ltris.data();
         bool mono = true;
         for (uint32_t l = 0; l < s->n_lights; ++l)
             for (uint32_t k = 0; k < s->lights[l].tri_count; ++k) {

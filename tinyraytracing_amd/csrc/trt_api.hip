@@ -315,18 +315,17 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     if (int e = upload(h.get(), s->nodes, (size_t)s->n_nodes, &h->sc.nodes)) return e;
     {
         std::vector<MaterialDev> mats(s->n_materials);
-        for (uint32_t i = 0; i < s->n_materials; ++i) {
-            const trt_material& m = s->materials[i];
-            MaterialDev& d = mats[i];
-            std::memcpy(d.Kd, m.Kd, 12); std::memcpy(d.Ks, m.Ks, 12); std::memcpy(d.Tr, m.Tr, 12);
-            d.Ns = m.Ns; d.Ni = m.Ni;
-            std::memcpy(d.radiance, m.radiance, 12);
-            d.is_emissive = m.is_emissive; d.tex = m.tex;
-        }
+        for (uint32_t i = 0; i < s->n_materials; ++i) mats[i] = makeMaterialDev(s->materials[i]);
         if (int e = upload(h.get(), mats.data(), mats.size(), &h->sc.materials)) return e;
     }
-    if (int e = upload(h.get(), s->lights, (size_t)s->n_lights, &h->sc.lights)) return e;
-    if (int e = upload(h.get(), s->light_tris, (size_t)s->n_light_tris, &h->sc.light_tris)) return e;
+    {
+        std::vector<LightDev> lights(s->n_lights);
+        for (uint32_t i = 0; i < s->n_lights; ++i) lights[i] = makeLightDev(s->lights[i]);
+        std::vector<LightTriDev> ltris(s->n_light_tris);
+        for (uint32_t i = 0; i < s->n_light_tris; ++i) ltris[i] = makeLightTriDev(s->light_tris[i]);
+        if (int e = upload(h.get(), lights.data(), lights.size(), &h->sc.lights)) return e;
+        if (int e = upload(h.get(), ltris.data(), ltris.size(), &h->sc.light_tris)) return e;
+    }
     {   // packed CDF for the bisection in lightSample; only when every light's CDF is non-decreasing and NaN-free
         std::vector<float> cum(s->n_light_tris);
         bool mono = true;

@@ -40,11 +40,6 @@ constexpr int TRT_TRACE_BLOCK = 256;
 #define TRT_LDS_STACK_MAX_LEVELS 16
 #endif
 constexpr int TRT_LDS_STACK_MAX = TRT_LDS_STACK_MAX_LEVELS;   // deepest LDS stack (x 256 lanes x 4 B per block); deeper levels spill to global
-// TRT_SHADE_SLOTS: output queues (shadow rays of consecutive lights, extension ray) that share one
-// reservation phase of k_shade (one barrier pair, atomics in parallel); more slots = more live registers
-#ifndef TRT_SHADE_SLOTS
-#define TRT_SHADE_SLOTS 2
-#endif
 #ifndef TRT_SHADE_BLOCK_THREADS
 #define TRT_SHADE_BLOCK_THREADS 512
 #endif
@@ -536,35 +531,28 @@ __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uin
     traceQueue<true, COUNT, DEPTH, SPILL, IMPL>(sc, sq.sa, sq.sb, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem);
 }
 
-// Block-wide stream compaction for up to S output queues at once: every thread calls it; a thread
-// with flag[k] receives the next free slot of queue k.  Wave rank from __ballot/popcount, wave offsets
-// through LDS, ONE global atomic per block and queue — issued by S different threads in the same phase,
-// so their latencies overlap and a block pays one barrier pair per S queues (a returning atomic on one
-// word sustains only ~88 per microsecond chip-wide: per-wave atomics would cost milliseconds per launch).
-// s_cnt holds 2 * S * (NW + 1) words; `parity` alternates between calls.
-template <int BLOCK, int S>
-__device__ inline void blockReserveMulti(const bool (&flag)[S], uint32_t* const (&counter)[S], uint32_t (&slot)[S], uint32_t* s_cnt, int parity)
+// Block-wide stream compaction slot: every thread calls it; threads with `flag`
+// receive consecutive slots of the output queue.  Wave rank from
+// __ballot/popcount, wave offsets through LDS, ONE global atomic per block.
+// s_cnt must hold 2 * (NW + 1) words; `parity` alternates between calls so two
+// barriers per call suffice.
+template <int BLOCK>
+__device__ inline uint32_t blockReserve(bool flag, uint32_t* counter, uint32_t* s_cnt, int parity)
 {
     constexpr int NW = BLOCK / 64;
-    uint32_t* s = s_cnt + parity * S * (NW + 1);
+    uint32_t* s = s_cnt + parity * (NW + 1);
+    const unsigned long long ballot = __ballot(flag);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t rank[S];
-#pragma unroll
-    for (int k = 0; k < S; ++k) {
-        const unsigned long long ballot = __ballot(flag[k]);
-        rank[k] = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-        if (lane == 0) s[k * (NW + 1) + wave] = (uint32_t)__popcll(ballot);
-    }
+    const uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) s[wave] = (uint32_t)__popcll(ballot);
     __syncthreads();
-    if (threadIdx.x < (uint32_t)S) {
-        uint32_t* sk = s + threadIdx.x * (NW + 1);
+    if (threadIdx.x == 0) {
         uint32_t tot = 0;
-        for (int w = 0; w < NW; ++w) { const uint32_t c = sk[w]; sk[w] = tot; tot += c; }
-        sk[NW] = tot ? atomicAdd(counter[threadIdx.x], tot) : 0u;
+        for (int w = 0; w < NW; ++w) { const uint32_t c = s[w]; s[w] = tot; tot += c; }
+        s[NW] = tot ? atomicAdd(counter, tot) : 0u;
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < S; ++k) slot[k] = s[k * (NW + 1) + NW] + s[k * (NW + 1) + wave] + rank[k];
+    return s[NW] + s[wave] + rank;
 }
 
 // ---------------------------------------------------------------- K3 ----
@@ -588,14 +576,12 @@ struct ShadeArgs {
 
 __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
 {
-    constexpr int S = TRT_SHADE_SLOTS;  // output queues served per reservation phase
-    __shared__ uint32_t s_cnt[2 * S * (TRT_SHADE_BLOCK / 64 + 1)];
+    __shared__ uint32_t s_cnt[2 * (TRT_SHADE_BLOCK / 64 + 1)];
     __shared__ uint32_t s_shaded, s_anyhit;
     if (threadIdx.x == 0) { s_shaded = 0; s_anyhit = 0; }
     __syncthreads();
     int parity = 0;
     uint32_t bounce_depth = 0;
-    const uint32_t nl = sc.n_lights;
     const uint32_t per_grid = gridDim.x * TRT_SHADE_BLOCK;
     // uniform trip count per block: every thread reaches every barrier
     for (uint32_t base = blockIdx.x * TRT_SHADE_BLOCK; base < A.n; base += per_grid) {
@@ -615,47 +601,30 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         if ((threadIdx.x & 63u) == 0 && ok_ballot) atomicAdd(&s_shaded, (uint32_t)__popcll(ok_ballot));
         if (__ballot(c.had_hit) && (threadIdx.x & 63u) == 0) s_anyhit = 1;
 
-        // Items 0..nl-1: one NEE shadow ray per light, in light order (pathTracing.cpp:34-74); item nl: the
-        // extension ray after RR(0.8) + nextRay (pathTracing.cpp:78-99).  The random draws happen in item
-        // order; S items share one reservation phase.
-        for (uint32_t g0 = 0; g0 <= nl; g0 += S) {
-            bool flag[S];
-            uint32_t* counter[S];
-            uint32_t slot[S];
-            f4 qa[S], qb[S], qc[S];
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const uint32_t item = g0 + k;
-                flag[k] = false;
-                counter[k] = A.next_count;
-                qa[k] = qb[k] = qc[k] = mk4(0, 0, 0, 0);
-                if (item < nl) {
-                    counter[k] = A.shadow_counts + item;
-                    f3 wo = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
-                    if (c.shade_ok && lightSample(sc, c.vx, c.m, item, c.rng, wo, contrib)) {
-                        flag[k] = true;
-                        const f3 w = c.beta * contrib;
-                        qa[k] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, wo.x);  // Q6: origin = hit point, no offset
-                        qb[k] = mk4(wo.y, wo.z, u2f(c.pid), 0.0f);
-                        qc[k] = mk4(w.x, w.y, w.z, 0.0f);
-                    }
-                } else if (item == nl) {
-                    flag[k] = shadeNext(c, A.max_depth, qa[k], qb[k], qc[k]);
-                }
-            }
-            blockReserveMulti<TRT_SHADE_BLOCK, S>(flag, counter, slot, s_cnt, parity);
+        // direct illumination: one shadow ray per light (pathTracing.cpp:34-74)
+        for (uint32_t li = 0; li < sc.n_lights; ++li) {
+            bool emit = false;
+            f3 wo = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
+            if (c.shade_ok) emit = lightSample(sc, c.vx, c.m, li, c.rng, wo, contrib);
+            const uint32_t slot = blockReserve<TRT_SHADE_BLOCK>(emit, A.shadow_counts + li, s_cnt, parity);
             parity ^= 1;
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const uint32_t item = g0 + k;
-                if (!flag[k]) continue;
-                f4* pa = item < nl ? A.sq[item < nl ? item : 0].sa : A.qout.ra;
-                f4* pb = item < nl ? A.sq[item < nl ? item : 0].sb : A.qout.rb;
-                f4* pc = item < nl ? A.sq[item < nl ? item : 0].sw : A.qout.bt;
-                pa[slot[k]] = qa[k];
-                pb[slot[k]] = qb[k];
-                pc[slot[k]] = qc[k];
+            if (emit) {
+                const f3 w = c.beta * contrib;
+                A.sq[li].sa[slot] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, wo.x);  // Q6: origin = hit point, no offset
+                A.sq[li].sb[slot] = mk4(wo.y, wo.z, u2f(c.pid), 0.0f);
+                A.sq[li].sw[slot] = mk4(w.x, w.y, w.z, 0.0f);
             }
+        }
+
+        // indirect illumination: RR(0.8) then nextRay (pathTracing.cpp:78-99)
+        f4 nra, nrb, nbt;
+        const bool emit_next = shadeNext(c, A.max_depth, nra, nrb, nbt);
+        const uint32_t slot = blockReserve<TRT_SHADE_BLOCK>(emit_next, A.next_count, s_cnt, parity);
+        parity ^= 1;
+        if (emit_next) {
+            A.qout.ra[slot] = nra;
+            A.qout.rb[slot] = nrb;
+            A.qout.bt[slot] = nbt;
         }
     }
     __syncthreads();

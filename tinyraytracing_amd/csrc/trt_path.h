@@ -72,13 +72,34 @@ struct alignas(16) TriShade {
     float vt[6];
     int32_t mat;
 };
-struct MaterialDev {
+// Table records are padded to multiples of 16 B and copied whole, so a lane fetches one with a few
+// 16-B loads instead of one dword load per field (k_shade is bound by load-instruction issue otherwise).
+struct alignas(16) MaterialDev {
     float Kd[3], Ks[3], Tr[3];
     float Ns, Ni;
     float radiance[3];
     int32_t is_emissive;
     int32_t tex;  // -1 = none
+    int32_t pad[4];
 };
+static_assert(sizeof(MaterialDev) == 80, "MaterialDev must be five 16-byte words");
+// trt_light_tri (19 floats) padded to 80 B
+struct alignas(16) LightTriDev {
+    float v[3][3];
+    float vn[3][3];
+    float cum_area;
+    float pad;
+};
+static_assert(sizeof(LightTriDev) == 80, "LightTriDev must be five 16-byte words");
+// trt_light (7 words) padded to 32 B
+struct alignas(16) LightDev {
+    int32_t mat;
+    float radiance[3];
+    float area;
+    uint32_t tri_first, tri_count;
+    uint32_t pad;
+};
+static_assert(sizeof(LightDev) == 32, "LightDev must be two 16-byte words");
 struct TextureDev {
     int32_t width, height;
     uint64_t offset;  // into tex_bytes
@@ -89,8 +110,8 @@ struct SceneDev {
     const TriIsect* tri_isect;
     const TriShade* tri_shade;
     const MaterialDev* materials;
-    const trt_light* lights;
-    const trt_light_tri* light_tris;
+    const LightDev* lights;
+    const LightTriDev* light_tris;
     const float* light_cum;  // light_tris[k].cum_area packed (the CDF of pathTracing.cpp:40); null = scan the structs
     const TextureDev* textures;
     const uint8_t* tex_bytes;
@@ -105,6 +126,33 @@ struct Hit {
     float u, v;      // barycentric weights of v1, v2
     uint32_t flags;  // TriIsect flags of the hit triangle: bit 0 emissive, bits 8.. material id
 };
+
+TRT_HD inline MaterialDev makeMaterialDev(const trt_material& m)
+{
+    MaterialDev d;
+    for (int k = 0; k < 3; ++k) { d.Kd[k] = m.Kd[k]; d.Ks[k] = m.Ks[k]; d.Tr[k] = m.Tr[k]; d.radiance[k] = m.radiance[k]; }
+    d.Ns = m.Ns; d.Ni = m.Ni;
+    d.is_emissive = m.is_emissive; d.tex = m.tex;
+    d.pad[0] = d.pad[1] = d.pad[2] = d.pad[3] = 0;
+    return d;
+}
+TRT_HD inline LightTriDev makeLightTriDev(const trt_light_tri& t)
+{
+    LightTriDev d;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) { d.v[a][b] = t.v[a][b]; d.vn[a][b] = t.vn[a][b]; }
+    d.cum_area = t.cum_area;
+    d.pad = 0.0f;
+    return d;
+}
+TRT_HD inline LightDev makeLightDev(const trt_light& l)
+{
+    LightDev d;
+    d.mat = l.mat;
+    for (int k = 0; k < 3; ++k) d.radiance[k] = l.radiance[k];
+    d.area = l.area; d.tri_first = l.tri_first; d.tri_count = l.tri_count; d.pad = 0;
+    return d;
+}
 
 // Build-time helper shared by trt_create and the hostsim: the 48-B record of one triangle.
 TRT_HD inline TriIsect makeTriIsect(const float* v9, int32_t mat, bool emissive)
@@ -388,23 +436,25 @@ TRT_HD inline Vertex makeVertex(const SceneDev& sc, const Hit& h, f3 o, f3 d, co
 // hit carries the light's material (pathTracing.cpp:55-70).
 TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const MaterialDev& m, uint32_t li, Stream& rng, f3& wo, f3& contrib)
 {
-    const trt_light L = sc.lights[li];
+    const LightDev L = sc.lights[li];
     const float rnd = rng.next() * sc.light0_area;  // Q3
     // first triangle whose cumulative area exceeds rnd (the linear scan of pathTracing.cpp:38-42); on a
     // non-decreasing CDF a bisection finds the same index
-    const trt_light_tri* lt = nullptr;
+    uint32_t pick = L.tri_count;
     if (sc.light_cum) {
         uint32_t lo = 0, hi = L.tri_count;
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
             if (rnd < sc.light_cum[L.tri_first + mid]) hi = mid; else lo = mid + 1;
         }
-        if (lo < L.tri_count) lt = &sc.light_tris[L.tri_first + lo];
+        pick = lo;
     } else {
         for (uint32_t k = 0; k < L.tri_count; ++k)
-            if (rnd < sc.light_tris[L.tri_first + k].cum_area) { lt = &sc.light_tris[L.tri_first + k]; break; }
+            if (rnd < sc.light_tris[L.tri_first + k].cum_area) { pick = k; break; }
     }
-    if (!lt) return false;
+    if (pick >= L.tri_count) return false;
+    const LightTriDev T = sc.light_tris[L.tri_first + pick];  // whole record: five 16-B loads
+    const LightTriDev* lt = &T;
     const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
     const float rs = (r1 + r2) + r3;
     const float p1 = r1 / rs, p2 = r2 / rs, p3 = r3 / rs;  // Q4
