@@ -153,7 +153,7 @@ typedef struct trt_params {
 
 #define TRT_MAX_KERNELS 8
 enum {
-    TRT_K_GEN_PRIMARY = 0,
+    TRT_K_GEN_PRIMARY = 0,  /* unused since primary-ray generation is fused into bounce 0 (always 0 launches) */
     TRT_K_TRACE_CLOSEST = 1,
     TRT_K_SHADE = 2,
     TRT_K_TRACE_SHADOW = 3,

@@ -156,8 +156,8 @@ uint32_t traceGrid(uint32_t n)
 // Traversal kernels: the LDS stack holds 8 or 16 levels without spill code when the scene's verified BVH
 // depth fits, else 16 levels + a global spill area (16 KiB per block keeps 8 waves per SIMD resident);
 // the wave driver (trt_kernels.h) is the static one for shallow trees, the scheduler one otherwise.
-template <bool COUNT>
-void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, const f4* rb, f4* hit, uint32_t n, DeviceStats* d_stats);
+template <bool COUNT, bool PRIMARY>
+void launchTraceClosest(const trt_handle* h, hipStream_t stream, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats);
 template <bool COUNT>
 void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats);
 
@@ -196,26 +196,26 @@ struct Timer {
     }
 };
 
-template <bool COUNT>
-void launchTraceClosest(const trt_handle* h, hipStream_t stream, const f4* ra, const f4* rb, f4* hit, uint32_t n, DeviceStats* d_stats)
+template <bool COUNT, bool PRIMARY>
+void launchTraceClosest(const trt_handle* h, hipStream_t stream, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats)
 {
     uint32_t* spill = (uint32_t*)h->spill.p;
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_closest<COUNT, 1, false, 0>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+    if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_closest<COUNT, 1, false, 0, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
     else if (h->trace_impl == 1) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 1>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 1, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 1, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 1, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
     }
     else if (h->trace_impl == 2) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 2>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 2>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 2>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 2, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 2, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 2, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
     }
     else if (h->trace_impl == 3) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 3>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 3>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 3>), g, b, 0, stream, h->sc, ra, rb, hit, n, spill, SPILL_STRIDE, d_stats);
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 3, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 3, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
+        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 3, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
     }
 }
 
@@ -457,18 +457,25 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         const uint32_t sc_count = std::min(s_chunk, (uint32_t)p->spp - s0);
         const uint32_t n0 = npix * sc_count;
         HIPC(hipMemsetAsync(d_counts, 0, counts_bytes, stream));
-        tm.begin(TRT_K_GEN_PRIMARY);
-        hipLaunchKernelGGL(k_gen_primary, dim3(std::min<uint32_t>((n0 + 255) / 256, 65536u)), dim3(256), 0, stream, h->sc, td, Q[0], Lacc, s0, n0);
-        tm.end();
-        st.launches[TRT_K_GEN_PRIMARY]++;
+        // bounce 0 needs no k_gen_primary launch: camera rays are generated inside the traversal and shade kernels
         st.rays_camera += n0;
 
         uint32_t n_active = n0;
         int cur = 0;
         for (uint32_t b = 0; n_active > 0 && b < MAX_BOUNCES; ++b) {
             tm.begin(TRT_K_TRACE_CLOSEST);
-            if (count) launchTraceClosest<true>(h, stream, Q[cur].ra, Q[cur].rb, hit, n_active, d_stats);
-            else launchTraceClosest<false>(h, stream, Q[cur].ra, Q[cur].rb, hit, n_active, d_stats);
+            RaySource src;
+            src.ra = Q[cur].ra;
+            src.rb = Q[cur].rb;
+            src.td = td;
+            src.s0 = s0;
+            if (b == 0) {
+                if (count) launchTraceClosest<true, true>(h, stream, src, hit, n_active, d_stats);
+                else launchTraceClosest<false, true>(h, stream, src, hit, n_active, d_stats);
+            } else {
+                if (count) launchTraceClosest<true, false>(h, stream, src, hit, n_active, d_stats);
+                else launchTraceClosest<false, false>(h, stream, src, hit, n_active, d_stats);
+            }
             tm.end();
             st.launches[TRT_K_TRACE_CLOSEST]++;
 
@@ -484,6 +491,7 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
             A.td = td;
             A.s0 = s0;
             A.max_depth = p->max_depth;
+            A.primary = b == 0 ? 1u : 0u;
             A.stats = d_stats;
             tm.begin(TRT_K_SHADE);
             hipLaunchKernelGGL(k_shade, dim3(std::min<uint32_t>((n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u)), dim3(TRT_SHADE_BLOCK), 0, stream, h->sc, A);
@@ -605,7 +613,10 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     HIPC(hipEventCreate(&e0));
     HIPC(hipEventCreate(&e1));
     HIPC(hipEventRecord(e0, nullptr));
-    launchTraceClosest<true>(h, nullptr, ra, rb, hit, n32, d_stats);
+    RaySource src{};
+    src.ra = ra;
+    src.rb = rb;
+    launchTraceClosest<true, false>(h, nullptr, src, hit, n32, d_stats);
     HIPC(hipEventRecord(e1, nullptr));
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());

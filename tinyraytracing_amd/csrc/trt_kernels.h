@@ -9,7 +9,7 @@
 //   shadow queue per light   sa = (o.xyz, d.x)  sb = (d.y, d.z, bits(path id), -)
 //                            sw = (w.r, w.g, w.b, -)   w = beta * unoccluded contribution
 //   accumulator Lacc[path id] = (L.r, L.g, L.b, -)
-// Per bounce: trace_closest -> shade (emits <= 1 extension ray and <= 1 shadow
+// Bounce 0 generates its camera rays in registers (no queue).  Per bounce: trace_closest -> shade (emits <= 1 extension ray and <= 1 shadow
 // ray per light, compacted with __ballot/popcount ranks + one atomic per block)
 // -> trace_shadow per light (in light order, so every path's sum has a fixed
 // order and the image is bit-reproducible).
@@ -113,28 +113,10 @@ __device__ inline unsigned long long waveSum(unsigned long long v)
 }
 
 // ---------------------------------------------------------------- K1 ----
-// Primary rays: main.cpp:88-95 + Camera::getRay (camera.cpp:19-28).
+// Primary rays (main.cpp:88-95 + Camera::getRay, camera.cpp:19-28) have no kernel of their own:
+// primaryRay() (trt_path.h) is a pure function of the path id, evaluated in registers by the bounce-0
+// traversal kernel (PRIMARY) and again by k_shade, so no camera-ray queue is written to or read from HBM.
 // path id i = s_local * npix + pixel-in-tile: a wave covers 64 neighbouring pixels.
-
-__global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, RayQueue q, f4* __restrict__ Lacc, uint32_t s0, uint32_t n)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t s_local = i / td.npix, pl = i - s_local * td.npix;
-        const uint32_t r = pl / (uint32_t)td.tile_w, c = pl - r * (uint32_t)td.tile_w;
-        const int y = td.rows[r], x = td.x0 + (int)c;
-        Stream rng;
-        rng.key = trt_rng_make_key(td.seed, (uint32_t)y * (uint32_t)td.width + (uint32_t)x, s0 + s_local);
-        rng.ctr = 0;
-        const float u1 = rng.next(), u2 = rng.next();
-        f3 o, d;
-        cameraRay(sc.cam, td.width, td.height, y, x, u1, u2, o, d);
-        q.ra[i] = mk4(o.x, o.y, o.z, d.x);
-        q.rb[i] = mk4(d.y, d.z, u2f(i), u2f(packMeta(rng.ctr, TRT_META_CAMERA, 0)));
-        q.bt[i] = mk4(1.0f, 1.0f, 1.0f, 0.0f);
-        Lacc[i] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-}
 
 // ------------------------------------------------------------ K2 / K4 ----
 // traverseBVH (bvh.cpp:146-245) for every queued ray.  Per ray, the node/leaf
@@ -155,6 +137,20 @@ __global__ __launch_bounds__(256) void k_gen_primary(SceneDev sc, TileDesc td, R
 #ifndef TRT_REFILL_MIN
 #define TRT_REFILL_MIN 16
 #endif
+
+// Where a traversal kernel takes ray `i` from: the queue in HBM, or (PRIMARY) the camera-ray generator.
+struct RaySource {
+    const f4* ra;
+    const f4* rb;
+    TileDesc td;
+    uint32_t s0;
+};
+template <bool PRIMARY>
+__device__ __forceinline__ void fetchRay(const SceneDev& sc, const RaySource& src, uint32_t i, f4& a, f4& b)
+{
+    if (PRIMARY) primaryRay(sc, src.td, src.s0, i, a, b);
+    else { a = src.ra[i]; b = src.rb[i]; }
+}
 
 constexpr uint32_t TRT_REF_IDLE = 0xFFFFFFFFu;  // lane holds no ray        } both have the leaf bit set and
 constexpr uint32_t TRT_REF_DONE = 0xFFFFFFFEu;  // ray finished, not stored } first >= 2^27 - 2: beyond TRT_MAX_TRIS, no builder emits them
@@ -195,8 +191,8 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
 // This is the reference's own visit set — both children, no culling by the best hit (bvh.cpp:146-175) —
 // so the counters equal the oracle's, and the result is the same as the ordered traversal's because
 // the leaf rule and the between-leaves rule are applied unchanged.
-template <bool SHADOW, bool COUNT>
-__device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+template <bool SHADOW, bool COUNT, bool PRIMARY>
+__device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                                   const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, DeviceStats* stats)
 {
     uint32_t n_inner = 0, n_tri = 0;
@@ -207,7 +203,8 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const f4* 
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < n;
         const uint32_t ii = valid ? i : n - 1;
-        const f4 a = ra[ii], b = rb[ii];
+        f4 a, b;
+        fetchRay<PRIMARY>(sc, src, ii, a, b);
         const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         uint32_t reach = valid ? 1u : 0u;  // bit k: the ray reaches inner node k
@@ -267,8 +264,8 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const f4* 
     }
 }
 
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL>
-__device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
+__device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
 {
@@ -280,7 +277,8 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const f4* _
     const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
     const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
     for (uint32_t i = lb * TRT_TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
-        const f4 a = ra[i], b = rb[i];
+        f4 a, b;
+        fetchRay<PRIMARY>(sc, src, i, a, b);
         const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
         if (!SHADOW) {
             hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
@@ -300,8 +298,8 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const f4* _
         }
     }
 }
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL>
-__device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
+__device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
 {
@@ -348,7 +346,8 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const f
                 const uint32_t rank = (uint32_t)__popcll(m_free & lower);
                 if (!working && next + rank < end) {
                     idx = next + rank;
-                    const f4 a = ra[idx], b = rb[idx];
+                    f4 a, b;
+                    fetchRay<PRIMARY>(sc, src, idx, a, b);
                     o = mk3(a.x, a.y, a.z);
                     d = mk3(a.w, b.x, b.y);
                     if (SHADOW) pid = f2u(b.z);
@@ -501,22 +500,24 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const f
     }
 }
 
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL>
-__device__ __forceinline__ void traceQueue(const SceneDev& sc, const f4* __restrict__ ra, const f4* __restrict__ rb, uint32_t n, f4* __restrict__ hit,
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
+__device__ __forceinline__ void traceQueue(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
 {
-    if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT>(sc, ra, rb, n, hit, sw, light_mat, Lacc, stats);
-    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL>(sc, ra, rb, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
-    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL>(sc, ra, rb, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+    if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats);
+    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
 }
 
-template <bool COUNT, int DEPTH, bool SPILL, int IMPL>
-__global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, const f4* __restrict__ ra, const f4* __restrict__ rb, f4* __restrict__ hit, uint32_t n,
+// PRIMARY: bounce 0 — ray i is the camera ray of path i, generated in registers (K1 of SURVEY.md §7 fused
+// into K2: no primary-ray queue is ever written or read).
+template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
+__global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
     __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
-    traceQueue<false, COUNT, DEPTH, SPILL, IMPL>(sc, ra, rb, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem);
+    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem);
 }
 
 // Shadow test of shade() (pathTracing.cpp:51-58): CLOSEST hit, visible iff
@@ -528,7 +529,11 @@ __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uin
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
     __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
-    traceQueue<true, COUNT, DEPTH, SPILL, IMPL>(sc, sq.sa, sq.sb, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+    RaySource src;
+    src.ra = sq.sa;
+    src.rb = sq.sb;
+    src.s0 = 0;
+    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem);
 }
 
 // Block-wide stream compaction slot: every thread calls it; threads with `flag`
@@ -571,6 +576,7 @@ struct ShadeArgs {
     TileDesc td;
     uint32_t s0;
     int32_t max_depth;
+    uint32_t primary;         // bounce 0: entry i is the camera ray of path i (not in HBM); Lacc is initialised here
     DeviceStats* stats;
 };
 
@@ -589,13 +595,22 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         ShadeCtx c;
         c.had_hit = c.shade_ok = c.add_L = false;
         if (i < A.n) {
-            shadeBegin(sc, A.td, A.s0, A.qin.ra[i], A.qin.rb[i], A.qin.bt[i], A.hit[i], c);
-            if (c.had_hit) bounce_depth = c.depth;
-            if (c.add_L) {
-                f4 L = A.Lacc[c.pid];
-                L.x = L.x + c.addL.x; L.y = L.y + c.addL.y; L.z = L.z + c.addL.z;
-                A.Lacc[c.pid] = L;
+            if (A.primary) {
+                // every path passes here exactly once, hit or miss: L starts at 0 (+ the radiance of a directly
+                // visible light, pathTracing.cpp:9-12 through main.cpp:101)
+                f4 ra, rb;
+                primaryRay(sc, A.td, A.s0, i, ra, rb);
+                shadeBegin(sc, A.td, A.s0, ra, rb, mk4(1.0f, 1.0f, 1.0f, 0.0f), A.hit[i], c);
+                A.Lacc[i] = c.add_L ? mk4(0.0f + c.addL.x, 0.0f + c.addL.y, 0.0f + c.addL.z, 0.0f) : mk4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                shadeBegin(sc, A.td, A.s0, A.qin.ra[i], A.qin.rb[i], A.qin.bt[i], A.hit[i], c);
+                if (c.add_L) {
+                    f4 L = A.Lacc[c.pid];
+                    L.x = L.x + c.addL.x; L.y = L.y + c.addL.y; L.z = L.z + c.addL.z;
+                    A.Lacc[c.pid] = L;
+                }
             }
+            if (c.had_hit) bounce_depth = c.depth;
         }
         const unsigned long long ok_ballot = __ballot(c.shade_ok);
         if ((threadIdx.x & 63u) == 0 && ok_ballot) atomicAdd(&s_shaded, (uint32_t)__popcll(ok_ballot));

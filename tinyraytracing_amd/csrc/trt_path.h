@@ -507,6 +507,24 @@ TRT_HD inline trt_rng_key pathKey(const TileDesc& td, uint32_t s0, uint32_t pid)
     return trt_rng_make_key(td.seed, pixel, s0 + s_local);
 }
 
+// The camera ray of path `pid` (main.cpp:88-95, camera.cpp:19-28) as the queue record (ra, rb): a pure
+// function of the path id, so bounce 0 never goes through HBM — the traversal kernel generates it and
+// k_shade generates the same bits again.
+TRT_HD inline void primaryRay(const SceneDev& sc, const TileDesc& td, uint32_t s0, uint32_t pid, f4& ra, f4& rb)
+{
+    const uint32_t s_local = pid / td.npix, pl = pid - s_local * td.npix;
+    const uint32_t r = pl / (uint32_t)td.tile_w, c = pl - r * (uint32_t)td.tile_w;
+    const int y = td.rows[r], x = td.x0 + (int)c;
+    Stream rng;
+    rng.key = trt_rng_make_key(td.seed, (uint32_t)y * (uint32_t)td.width + (uint32_t)x, s0 + s_local);
+    rng.ctr = 0;
+    const float u1 = rng.next(), u2 = rng.next();  // jitter x, then y (main.cpp:92-93)
+    f3 o, d;
+    cameraRay(sc.cam, td.width, td.height, y, x, u1, u2, o, d);
+    ra = mk4(o.x, o.y, o.z, d.x);
+    rb = mk4(d.y, d.z, u2f(pid), u2f(packMeta(rng.ctr, TRT_META_CAMERA, 0)));
+}
+
 struct ShadeCtx {
     bool had_hit;   // the traced ray hit something
     bool shade_ok;  // ... a non-emissive surface: NEE + continuation follow
