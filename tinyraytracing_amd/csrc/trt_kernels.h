@@ -27,6 +27,11 @@ namespace trtd {
 // Build-time tuning knobs (A/B variants are built by `make variants` and picked with TRT_HIP_LIB):
 //   TRT_TRACE_MINWAVES  second __launch_bounds__ argument of the traversal kernels (0 = leave it to the compiler)
 //   TRT_PREFETCH        (trt_path.h) fetch the next triangle record of a leaf while the current one is tested
+// TRT_STACK_TENTRY: keep the box entry distance with every stack entry (bf16, +2 B per level and lane) and
+// cull at pop time (persistent drivers)
+#ifndef TRT_STACK_TENTRY
+#define TRT_STACK_TENTRY 0
+#endif
 #ifndef TRT_TRACE_MINWAVES
 #define TRT_TRACE_MINWAVES 0
 #endif
@@ -96,6 +101,14 @@ struct LdsStack {
         if (sp >= DEPTH) v = spill[(size_t)(sp - DEPTH) * spill_stride];
         return v;
     }
+#if TRT_STACK_TENTRY
+    // Box entry distance of every LDS-resident entry, as the upper 16 bits of the float (for t >= 0 that
+    // rounds DOWN, so "entry > best" on it can only under-cull, never drop a node that might still win).
+    // At pop time a subtree whose entry is strictly beyond the current best hit is skipped without fetching it.
+    uint16_t* lds_t;  // &smem_t[threadIdx.x]
+    __device__ void pushT(int sp, float t) { if (sp < DEPTH) lds_t[sp * TRT_TRACE_BLOCK] = (uint16_t)(f2u(t) >> 16); }
+    __device__ float popT(int sp) const { return sp < DEPTH ? u2f((uint32_t)lds_t[sp * TRT_TRACE_BLOCK] << 16) : 0.0f; }
+#endif
 };
 
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a
@@ -307,6 +320,9 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
     stk.lds = smem + threadIdx.x;
     stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
     stk.spill_stride = spill_stride;
+#if TRT_STACK_TENTRY
+    stk.lds_t = reinterpret_cast<uint16_t*>(smem + DEPTH * TRT_TRACE_BLOCK) + threadIdx.x;
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lower = (1ull << lane) - 1ull;
     // contiguous queue slice of this wave (XCD-aware: neighbouring slices share an L2)
@@ -444,6 +460,9 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                 h1 = h1 && !(e1 > best_t);
                 if (h0 && h1) {
                     const bool swap = e1 < e0;
+#if TRT_STACK_TENTRY
+                    stk.pushT(sp, swap ? e0 : e1);
+#endif
                     stk.push(sp++, swap ? child0 : child1);
                     cur = swap ? child1 : child0;
                     lk = 0; lt = TRT_INF; li = -1;
@@ -483,8 +502,16 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             }
         }
         if (adv) {
+#if TRT_STACK_TENTRY
+            cur = TRT_REF_DONE;
+            while (sp != 0) {
+                --sp;
+                if (!(stk.popT(sp) > best_t)) { cur = stk.pop(sp); break; }  // else: strictly beyond the best hit, drop it unfetched
+            }
+#else
             if (sp == 0) cur = TRT_REF_DONE;
             else cur = stk.pop(--sp);
+#endif
             lk = 0; lt = TRT_INF; li = -1;
         }
         }
@@ -516,7 +543,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
-    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
+    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK + (TRT_STACK_TENTRY ? DEPTH * TRT_TRACE_BLOCK / 2 : 0)];
     traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem);
 }
 
@@ -528,7 +555,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
-    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
+    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK + (TRT_STACK_TENTRY ? DEPTH * TRT_TRACE_BLOCK / 2 : 0)];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;
