@@ -46,7 +46,7 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h 
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options
-VARIANTS := te16=-DTRT_STACK_TENTRY=1 te12=-DTRT_STACK_TENTRY=1+-DTRT_LDS_STACK_MAX_LEVELS=12
+VARIANTS := sw5=-DTRT_SHADE_MINWAVES=5
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
 	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \
