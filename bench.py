@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--tris", type=int, default=None, help="triangle count of the synthetic scenes")
-    ap.add_argument("--leaf", type=int, default=4, help="triangles per BVH leaf (the reference uses 8)")
+    ap.add_argument("--leaf", type=int, default=None, help="triangles per BVH leaf (the reference uses 8); default: 8 for scenes of <= 64 triangles, else 4")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=None)
     ap.add_argument("--mem-gb", type=float, default=0.0, help="HBM budget for path state (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -169,7 +169,7 @@ def main():
             "dtype": "f32", "data": f"scene '{a.scene}' ({WORKLOADS[a.scene]}), counter RNG seed {seed:#x}",
             "config": {"workload": f"{WORKLOADS[a.scene]}, {a.width}x{a.height}, {a.spp} spp", "scene": a.scene, "width": a.width,
                        "height": a.height, "spp": a.spp, "triangles": scene.info["n_triangles"], "bvh_nodes": scene.arrays()["n_nodes"],
-                       "leaf_num": a.leaf, "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
+                       "leaf_num": a.leaf if a.leaf is not None else (T.TINY_LEAF if scene.info["n_triangles"] <= 64 else T.DEFAULT_LEAF), "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
             "rays_per_step": rays_total // a.steps,
             "rays_rank0": {"camera": st.rays_camera, "shadow": st.rays_shadow, "indirect": st.rays_indirect},
             "device_render_ms_per_step_rank0": round(render_ms / a.steps, 3),

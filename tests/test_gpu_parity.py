@@ -66,6 +66,33 @@ def test_trace_soup_deep_bvh(renderer_factory):
     assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
 
 
+@pytest.mark.parametrize("impl", ["1", "2", "3"])
+def test_every_wave_driver_gives_the_same_image(impl, monkeypatch):
+    """TRT_TRACE_IMPL forces the static / while-while / scheduler traversal driver (trt_kernels.h); the library
+    picks one per scene, and all of them must reproduce the oracle."""
+    monkeypatch.setenv("TRT_TRACE_IMPL", impl)
+    s = get_scene("veach-mis", 96, 54)
+    r = T.Renderer(s, 0)
+    p = T.make_params(96, 54, 8, 77)
+    img, st = r.render(p)
+    ref, ost = O.render(s.flat, p)
+    r.close()
+    assert_same_image(img, ref, f"impl {impl}")
+    assert st.rays == ost.rays
+
+
+def test_tiny_scene_uniform_walk_and_forced_per_ray_traversal(monkeypatch):
+    s = get_scene("back", 64, 64)
+    p = T.make_params(64, 64, 8, 5)
+    ref, _ = O.render(s.flat, p)
+    for impl in ("0", "1", "3"):
+        monkeypatch.setenv("TRT_TRACE_IMPL", impl)
+        r = T.Renderer(s, 0)
+        img, _ = r.render(p)
+        r.close()
+        assert_same_image(img, ref, f"back impl {impl}")
+
+
 # ------------------------------------------------------------------ images: the whole loop
 @pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
 def test_image_matches_golden(name, renderer_factory):

@@ -27,6 +27,7 @@ _BUILDERS = {"sweep": 0, "binned": 1, "auto": 2}
 # Triangles per BVH leaf.  The reference calls buildBVH(..., 8) (main.cpp:76); on the GPU 4 measured faster on every
 # scene larger than the Cornell box, and the topology is free: only nearest-hit + tie rules matter.
 DEFAULT_LEAF = 4
+TINY_LEAF = 8
 
 
 class TrtError(RuntimeError):
@@ -53,7 +54,7 @@ class Scene:
         return cls(h)
 
     @classmethod
-    def named(cls, name, width=0, height=0, leaf_num=DEFAULT_LEAF, builder="auto", n=None, seed=None):
+    def named(cls, name, width=0, height=0, leaf_num=None, builder="auto", n=None, seed=None):
         """Shipped and synthetic scenes: back, veach-mis, staircase, soup (n random triangles in
         the back box, BASELINE config 3), blob (displaced geodesic sphere, config 5)."""
         if name in ("back", "veach-mis", "staircase"):
@@ -69,6 +70,10 @@ class Scene:
                 s._check(s._lib.trth_scene_add_blob(s._h, SEED_BLOB if seed is None else seed, 10_000_000 if n is None else int(n)))
         else:
             raise TrtError(f"unknown scene {name!r}")
+        if leaf_num is None:
+            # tiny scenes are walked wave-uniformly (every node, every triangle: trt_kernels.h IMPL 0), where fewer,
+            # fuller leaves are cheaper; everything else is traversed per ray, where 4 measured best
+            leaf_num = TINY_LEAF if s.info["n_triangles"] <= 64 else DEFAULT_LEAF
         s.build_bvh(leaf_num, builder)
         return s
 
