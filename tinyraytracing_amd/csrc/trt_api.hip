@@ -69,6 +69,10 @@ struct trt_handle {
     int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
     uint32_t tail_n = 32768;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
     DevBuf arena, spill, small_buf, out_buf, io_buf;
+    size_t spill_words_per_slot = 0;
+    hipStream_t slot_streams[2] = {nullptr, nullptr};  // one per concurrent pass (trt_render_device)
+    int n_slots = 2;                                   // TRT_SLOTS=1 in the environment disables the overlap
+    uint32_t* pinned_counts = nullptr;                 // host-pinned landing zone of the per-bounce queue lengths
     std::vector<hipEvent_t> events;
     ~trt_handle()
     {
@@ -79,6 +83,8 @@ struct trt_handle {
         out_buf.release();
         io_buf.release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        for (hipStream_t st : slot_streams) if (st) (void)hipStreamDestroy(st);
+        if (pinned_counts) (void)hipHostFree(pinned_counts);
     }
 };
 
@@ -157,17 +163,17 @@ uint32_t traceGrid(uint32_t n)
 // depth fits, else 16 levels + a global spill area (16 KiB per block keeps 8 waves per SIMD resident);
 // the wave driver (trt_kernels.h) is the static one for shallow trees, the scheduler one otherwise.
 template <bool COUNT, bool PRIMARY>
-void launchTraceClosest(const trt_handle* h, hipStream_t stream, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats);
+void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats);
 template <bool COUNT>
-void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats);
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats);
 
 struct Timer {
     trt_handle* h;
-    hipStream_t stream;
     bool on;
     size_t used = 0;
     struct Span { int k; size_t e0, e1; };
     std::vector<Span> spans;
+    static constexpr size_t RESERVED = 3;  // render begin / end / resolve chain
     hipEvent_t get(size_t i)
     {
         while (h->events.size() <= i) {
@@ -177,29 +183,28 @@ struct Timer {
         }
         return h->events[i];
     }
-    // events 0/1 bracket the whole render; per-kernel spans only with TRT_FLAG_TIMING
-    void begin(int k)
+    // per-kernel spans only with TRT_FLAG_TIMING; recorded on the stream the kernel is launched on
+    void begin(int k, hipStream_t stream)
     {
         if (!on) return;
-        hipEvent_t e = get(2 + used);
+        hipEvent_t e = get(RESERVED + used);
         if (e) (void)hipEventRecord(e, stream);
-        spans.push_back({k, 2 + used, 0});
+        spans.push_back({k, RESERVED + used, 0});
         used++;
     }
-    void end()
+    void end(hipStream_t stream)
     {
         if (!on) return;
-        hipEvent_t e = get(2 + used);
+        hipEvent_t e = get(RESERVED + used);
         if (e) (void)hipEventRecord(e, stream);
-        spans.back().e1 = 2 + used;
+        spans.back().e1 = RESERVED + used;
         used++;
     }
 };
 
 template <bool COUNT, bool PRIMARY>
-void launchTraceClosest(const trt_handle* h, hipStream_t stream, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats)
+void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats)
 {
-    uint32_t* spill = (uint32_t*)h->spill.p;
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_closest<COUNT, 1, false, 0, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
     else if (h->trace_impl == 1) {
@@ -220,9 +225,8 @@ void launchTraceClosest(const trt_handle* h, hipStream_t stream, const RaySource
 }
 
 template <bool COUNT>
-void launchTraceShadow(const trt_handle* h, hipStream_t stream, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats)
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats)
 {
-    uint32_t* spill = (uint32_t*)h->spill.p;
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_shadow<COUNT, 1, false, 0>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
     else if (h->trace_impl == 1) {
@@ -361,7 +365,11 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
     const uint32_t spill_levels = depth > (uint32_t)TRT_LDS_STACK_MAX ? depth - TRT_LDS_STACK_MAX + 1 : 1;
-    if (int e = h->spill.ensure((size_t)spill_levels * SPILL_STRIDE * sizeof(uint32_t))) return e;
+    h->spill_words_per_slot = (size_t)spill_levels * SPILL_STRIDE;
+    if (int e = h->spill.ensure(h->spill_words_per_slot * 2 * sizeof(uint32_t))) return e;  // one area per concurrent pass
+    for (hipStream_t& st : h->slot_streams) HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPC(hipHostMalloc((void**)&h->pinned_counts, 2 * 2 * COUNT_ROW * sizeof(uint32_t), hipHostMallocDefault));
+    if (const char* e = std::getenv("TRT_SLOTS")) h->n_slots = std::atoi(e) >= 2 ? 2 : 1;
     *out = h.release();
     return TRT_OK;
 }
@@ -372,6 +380,28 @@ void trt_destroy(trt_handle* h)
     (void)hipSetDevice(h->device);
     delete h;
 }
+
+// One pass = all bounces of `sc_count` samples of every pixel of the tile.  Up to N_SLOTS passes are in
+// flight at once, each on its own stream with its own queues: while one pass sits in the latency-bound
+// shade kernel or in the host round trip that reads the queue lengths back, the other keeps the CUs busy
+// with traversal.  Passes are independent (every sample has its own RNG stream and its own Lacc entry);
+// only the per-pixel accumulation is ordered, so the resolves are issued strictly in pass order.
+namespace {
+constexpr int N_SLOTS = 2;
+struct PassSlot {
+    hipStream_t stream = nullptr;
+    RayQueue Q[2];
+    f4* hit = nullptr;
+    f4* Lacc = nullptr;
+    ShadowQueue SQ[TRT_MAX_LIGHTS];
+    uint32_t* d_counts = nullptr;
+    uint32_t* host_counts = nullptr;  // pinned
+    uint32_t* spill = nullptr;
+    enum State { IDLE, ISSUE, WAIT, RESOLVE } state = IDLE;
+    uint32_t chunk = 0, s0 = 0, sc_count = 0, n_active = 0, b = 0;
+    int cur = 0;
+};
+}  // namespace
 
 int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* hip_stream, trt_stats* stats_out)
 {
@@ -391,7 +421,7 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     if (npix64 > 0x7FFFFFFFull) return fail(TRT_EINVAL, "tile too large");
     const uint32_t npix = (uint32_t)npix64;
 
-    // ---- chunking: how many samples of every pixel are in flight at once ----
+    // ---- chunking: how many samples of every pixel one pass holds; >= N_SLOTS passes when spp allows ----
     const uint64_t bytes_per_path = 2ull * 48 + 16 + 16 + (uint64_t)nl * 48;
     uint64_t budget = p->mem_budget;
     if (!budget) {
@@ -399,36 +429,48 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         HIPC(hipMemGetInfo(&free_b, &total_b));
         budget = std::min<uint64_t>((uint64_t)(free_b + h->arena.bytes) / 2, 32ull << 30);
     }
+    const int n_slots = (p->spp >= 2 && h->n_slots > 1) ? N_SLOTS : 1;
     uint64_t max_paths = std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull);
     if (max_paths < npix) return fail(TRT_ENOMEM, "mem_budget too small for one sample of every pixel of the tile; render smaller tiles");
+    if (n_slots > 1 && max_paths / n_slots >= npix) max_paths /= n_slots;  // each slot gets its share of the budget
+    const int slots_used = (max_paths * n_slots <= std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull)) ? n_slots : 1;
     uint32_t s_chunk = (uint32_t)std::min<uint64_t>((uint64_t)p->spp, max_paths / npix);
-    const uint32_t n_chunks = ((uint32_t)p->spp + s_chunk - 1) / s_chunk;
+    uint32_t n_chunks = ((uint32_t)p->spp + s_chunk - 1) / s_chunk;
+    if (slots_used > 1 && n_chunks < (uint32_t)slots_used) n_chunks = (uint32_t)std::min<uint32_t>((uint32_t)slots_used, (uint32_t)p->spp);
     s_chunk = ((uint32_t)p->spp + n_chunks - 1) / n_chunks;
+    n_chunks = ((uint32_t)p->spp + s_chunk - 1) / s_chunk;
     const uint64_t N = (uint64_t)npix * s_chunk;
 
-    // ---- carve the arena -------------------------------------------------------
+    // ---- carve the arena: one set of queues per slot -------------------------------
     const size_t q16 = (size_t)N * sizeof(f4);
-    if (int e = h->arena.ensure(q16 * (3 * 2 + 1 + 1 + 3 * (size_t)nl))) return e;
-    f4* base = (f4*)h->arena.p;
-    auto take = [&]() { f4* r = base; base += N; return r; };
-    RayQueue Q[2];
-    for (int k = 0; k < 2; ++k) { Q[k].ra = take(); Q[k].rb = take(); Q[k].bt = take(); }
-    f4* hit = take();
-    f4* Lacc = take();
-    ShadowQueue SQ[TRT_MAX_LIGHTS] = {};
-    for (uint32_t l = 0; l < nl; ++l) { SQ[l].sa = take(); SQ[l].sb = take(); SQ[l].sw = take(); }
-
-    // small buffers: rows | counts | device stats | double accumulator
+    const size_t per_slot = q16 * (3 * 2 + 1 + 1 + 3 * (size_t)nl);
+    if (int e = h->arena.ensure(per_slot * (size_t)slots_used)) return e;
     const size_t rows_bytes = (rows.size() * sizeof(int32_t) + 255) & ~(size_t)255;
     const size_t counts_bytes = (size_t)(MAX_BOUNCES + 2) * COUNT_ROW * sizeof(uint32_t);
     const size_t stats_bytes = 256;
     const size_t acc_bytes = (size_t)npix * 3 * sizeof(double);
-    if (int e = h->small_buf.ensure(rows_bytes + counts_bytes + stats_bytes + acc_bytes)) return e;
+    if (int e = h->small_buf.ensure(rows_bytes + counts_bytes * N_SLOTS + stats_bytes + acc_bytes)) return e;
     char* sb = (char*)h->small_buf.p;
     int32_t* d_rows = (int32_t*)sb;
-    uint32_t* d_counts = (uint32_t*)(sb + rows_bytes);
-    DeviceStats* d_stats = (DeviceStats*)(sb + rows_bytes + counts_bytes);
-    double* d_acc = (double*)(sb + rows_bytes + counts_bytes + stats_bytes);
+    DeviceStats* d_stats = (DeviceStats*)(sb + rows_bytes + counts_bytes * N_SLOTS);
+    double* d_acc = (double*)(sb + rows_bytes + counts_bytes * N_SLOTS + stats_bytes);
+
+    PassSlot slots[N_SLOTS];
+    for (int k = 0; k < slots_used; ++k) {
+        PassSlot& S = slots[k];
+        S.stream = h->slot_streams[k];
+        f4* base = (f4*)((char*)h->arena.p + per_slot * (size_t)k);
+        auto take = [&]() { f4* r = base; base += N; return r; };
+        for (int q = 0; q < 2; ++q) { S.Q[q].ra = take(); S.Q[q].rb = take(); S.Q[q].bt = take(); }
+        S.hit = take();
+        S.Lacc = take();
+        for (uint32_t l = 0; l < (uint32_t)TRT_MAX_LIGHTS; ++l) S.SQ[l] = ShadowQueue{nullptr, nullptr, nullptr};
+        for (uint32_t l = 0; l < nl; ++l) { S.SQ[l].sa = take(); S.SQ[l].sb = take(); S.SQ[l].sw = take(); }
+        S.d_counts = (uint32_t*)(sb + rows_bytes + counts_bytes * (size_t)k);
+        S.host_counts = h->pinned_counts + (size_t)k * 2 * COUNT_ROW;
+        S.spill = (uint32_t*)h->spill.p + (size_t)k * h->spill_words_per_slot;
+    }
+
     HIPC(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIPC(hipMemsetAsync(d_stats, 0, sizeof(DeviceStats), stream));
     HIPC(hipMemsetAsync(d_acc, 0, acc_bytes, stream));
@@ -443,109 +485,144 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     td.seed = p->seed;
     td.spp = (uint32_t)p->spp;
 
-    Timer tm{h, stream, (p->flags & TRT_FLAG_TIMING) != 0};
+    Timer tm{h, (p->flags & TRT_FLAG_TIMING) != 0};
     trt_stats st;
     std::memset(&st, 0, sizeof(st));
-    hipEvent_t ev_begin = tm.get(0), ev_end = tm.get(1);
-    if (!ev_begin || !ev_end) return fail(TRT_EHIP, "hipEventCreate failed");
+    // events 0/1 bracket the render on the caller's stream, 2 chains the ordered resolves
+    hipEvent_t ev_begin = tm.get(0), ev_end = tm.get(1), ev_resolved = tm.get(2);
+    if (!ev_begin || !ev_end || !ev_resolved) return fail(TRT_EHIP, "hipEventCreate failed");
     HIPC(hipEventRecord(ev_begin, stream));
+    for (int k = 0; k < slots_used; ++k) HIPC(hipStreamWaitEvent(slots[k].stream, ev_begin, 0));
 
-    std::vector<uint32_t> host_counts(2 * COUNT_ROW);
-    uint32_t deepest = 0;
-    for (uint32_t chunk = 0; chunk < n_chunks; ++chunk) {
-        const uint32_t s0 = chunk * s_chunk;
-        const uint32_t sc_count = std::min(s_chunk, (uint32_t)p->spp - s0);
-        const uint32_t n0 = npix * sc_count;
-        HIPC(hipMemsetAsync(d_counts, 0, counts_bytes, stream));
-        // bounce 0 needs no k_gen_primary launch: camera rays are generated inside the traversal and shade kernels
-        st.rays_camera += n0;
-
-        uint32_t n_active = n0;
-        int cur = 0;
-        for (uint32_t b = 0; n_active > 0 && b < MAX_BOUNCES; ++b) {
-            tm.begin(TRT_K_TRACE_CLOSEST);
-            RaySource src;
-            src.ra = Q[cur].ra;
-            src.rb = Q[cur].rb;
-            src.td = td;
-            src.s0 = s0;
-            if (b == 0) {
-                if (count) launchTraceClosest<true, true>(h, stream, src, hit, n_active, d_stats);
-                else launchTraceClosest<false, true>(h, stream, src, hit, n_active, d_stats);
-            } else {
-                if (count) launchTraceClosest<true, false>(h, stream, src, hit, n_active, d_stats);
-                else launchTraceClosest<false, false>(h, stream, src, hit, n_active, d_stats);
-            }
-            tm.end();
-            st.launches[TRT_K_TRACE_CLOSEST]++;
-
-            ShadeArgs A;
-            A.qin = Q[cur];
-            A.hit = hit;
-            A.n = n_active;
-            A.qout = Q[cur ^ 1];
-            for (int l = 0; l < TRT_MAX_LIGHTS; ++l) A.sq[l] = SQ[l];
-            A.next_count = d_counts + (size_t)(b + 1) * COUNT_ROW;
-            A.shadow_counts = d_counts + (size_t)b * COUNT_ROW + 1;
-            A.Lacc = Lacc;
-            A.td = td;
-            A.s0 = s0;
-            A.max_depth = p->max_depth;
-            A.primary = b == 0 ? 1u : 0u;
-            A.stats = d_stats;
-            tm.begin(TRT_K_SHADE);
-            hipLaunchKernelGGL(k_shade, dim3(std::min<uint32_t>((n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u)), dim3(TRT_SHADE_BLOCK), 0, stream, h->sc, A);
-            tm.end();
-            st.launches[TRT_K_SHADE]++;
-
-            // queue lengths of this bounce's shadow rays and of the next bounce
-            HIPC(hipMemcpyAsync(host_counts.data(), d_counts + (size_t)b * COUNT_ROW, 2 * COUNT_ROW * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIPC(hipStreamSynchronize(stream));
-            for (uint32_t l = 0; l < nl; ++l) {
-                const uint32_t ns = host_counts[1 + l];
-                if (ns > n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");
-                if (!ns) continue;
-                tm.begin(TRT_K_TRACE_SHADOW);
-                if (count) launchTraceShadow<true>(h, stream, SQ[l], ns, h->light_mats[l], Lacc, d_stats);
-                else launchTraceShadow<false>(h, stream, SQ[l], ns, h->light_mats[l], Lacc, d_stats);
-                tm.end();
-                st.launches[TRT_K_TRACE_SHADOW]++;
-                st.rays_shadow += ns;
-            }
-            const uint32_t n_next = host_counts[COUNT_ROW];
-            if (n_next > n_active) return fail(TRT_EHIP, "internal error: queue grew");
-            st.rays_indirect += n_next;
-            n_active = n_next;
-            cur ^= 1;
-            deepest = std::max(deepest, b);
-            if (n_active > 0 && n_active <= h->tail_n) {
-                // few paths left: finish them in one launch (k_tail) instead of ~3 launches + a sync per bounce
-                TailArgs TA;
-                TA.q = Q[cur];
-                TA.n = n_active;
-                TA.Lacc = Lacc;
-                TA.td = td;
-                TA.s0 = s0;
-                TA.max_depth = p->max_depth;
-                TA.spill = (uint32_t*)h->spill.p;
-                TA.spill_stride = SPILL_STRIDE;
-                TA.stats = d_stats;
-                tm.begin(TRT_K_TAIL);
-                if (count) hipLaunchKernelGGL(k_tail<true>, dim3(traceGrid(n_active)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, TA);
-                else hipLaunchKernelGGL(k_tail<false>, dim3(traceGrid(n_active)), dim3(TRT_TRACE_BLOCK), 0, stream, h->sc, TA);
-                tm.end();
-                st.launches[TRT_K_TAIL]++;
-                n_active = 0;
-            }
+    uint32_t next_chunk = 0, resolved_upto = 0;
+    auto startPass = [&](PassSlot& S) -> int {
+        if (next_chunk >= n_chunks) { S.state = PassSlot::IDLE; return TRT_OK; }
+        S.chunk = next_chunk++;
+        S.s0 = S.chunk * s_chunk;
+        S.sc_count = std::min(s_chunk, (uint32_t)p->spp - S.s0);
+        S.n_active = npix * S.sc_count;
+        S.b = 0;
+        S.cur = 0;
+        HIPC(hipMemsetAsync(S.d_counts, 0, counts_bytes, S.stream));
+        st.rays_camera += S.n_active;  // bounce 0 generates its camera rays inside the traversal and shade kernels
+        S.state = PassSlot::ISSUE;
+        return TRT_OK;
+    };
+    // trace + shade of the slot's current bounce, then the queue lengths on their way to the host
+    auto issueFront = [&](PassSlot& S) -> int {
+        RaySource src;
+        src.ra = S.Q[S.cur].ra;
+        src.rb = S.Q[S.cur].rb;
+        src.td = td;
+        src.s0 = S.s0;
+        tm.begin(TRT_K_TRACE_CLOSEST, S.stream);
+        if (S.b == 0) {
+            if (count) launchTraceClosest<true, true>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats);
+            else launchTraceClosest<false, true>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats);
+        } else {
+            if (count) launchTraceClosest<true, false>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats);
+            else launchTraceClosest<false, false>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats);
         }
-        tm.begin(TRT_K_RESOLVE);
-        hipLaunchKernelGGL(k_resolve, dim3(std::min<uint32_t>((npix + 255) / 256, 65536u)), dim3(256), 0, stream, Lacc, d_acc, npix, sc_count, (float)p->spp);
-        tm.end();
+        tm.end(S.stream);
+        st.launches[TRT_K_TRACE_CLOSEST]++;
+
+        ShadeArgs A;
+        A.qin = S.Q[S.cur];
+        A.hit = S.hit;
+        A.n = S.n_active;
+        A.qout = S.Q[S.cur ^ 1];
+        for (int l = 0; l < TRT_MAX_LIGHTS; ++l) A.sq[l] = S.SQ[l];
+        A.next_count = S.d_counts + (size_t)(S.b + 1) * COUNT_ROW;
+        A.shadow_counts = S.d_counts + (size_t)S.b * COUNT_ROW + 1;
+        A.Lacc = S.Lacc;
+        A.td = td;
+        A.s0 = S.s0;
+        A.max_depth = p->max_depth;
+        A.primary = S.b == 0 ? 1u : 0u;
+        A.stats = d_stats;
+        tm.begin(TRT_K_SHADE, S.stream);
+        hipLaunchKernelGGL(k_shade, dim3(std::min<uint32_t>((S.n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u)), dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A);
+        tm.end(S.stream);
+        st.launches[TRT_K_SHADE]++;
+        HIPC(hipMemcpyAsync(S.host_counts, S.d_counts + (size_t)S.b * COUNT_ROW, 2 * COUNT_ROW * sizeof(uint32_t), hipMemcpyDeviceToHost, S.stream));
+        S.state = PassSlot::WAIT;
+        return TRT_OK;
+    };
+    // queue lengths are back: shadow rays of this bounce, then the next bounce / the tail / the end of the pass
+    auto completeBounce = [&](PassSlot& S) -> int {
+        HIPC(hipStreamSynchronize(S.stream));
+        for (uint32_t l = 0; l < nl; ++l) {
+            const uint32_t ns = S.host_counts[1 + l];
+            if (ns > S.n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");
+            if (!ns) continue;
+            tm.begin(TRT_K_TRACE_SHADOW, S.stream);
+            if (count) launchTraceShadow<true>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats);
+            else launchTraceShadow<false>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats);
+            tm.end(S.stream);
+            st.launches[TRT_K_TRACE_SHADOW]++;
+            st.rays_shadow += ns;
+        }
+        const uint32_t n_next = S.host_counts[COUNT_ROW];
+        if (n_next > S.n_active) return fail(TRT_EHIP, "internal error: queue grew");
+        st.rays_indirect += n_next;
+        S.n_active = n_next;
+        S.cur ^= 1;
+        S.b++;
+        if (S.n_active > 0 && (S.n_active <= h->tail_n || S.b >= MAX_BOUNCES)) {
+            // few paths left: finish them in one launch (k_tail) instead of ~3 launches + a host round trip per bounce
+            TailArgs TA;
+            TA.q = S.Q[S.cur];
+            TA.n = S.n_active;
+            TA.Lacc = S.Lacc;
+            TA.td = td;
+            TA.s0 = S.s0;
+            TA.max_depth = p->max_depth;
+            TA.spill = S.spill;
+            TA.spill_stride = SPILL_STRIDE;
+            TA.stats = d_stats;
+            tm.begin(TRT_K_TAIL, S.stream);
+            if (count) hipLaunchKernelGGL(k_tail<true>, dim3(traceGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+            else hipLaunchKernelGGL(k_tail<false>, dim3(traceGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+            tm.end(S.stream);
+            st.launches[TRT_K_TAIL]++;
+            S.n_active = 0;
+        }
+        S.state = S.n_active ? PassSlot::ISSUE : PassSlot::RESOLVE;
+        return TRT_OK;
+    };
+    // per-pixel accumulation in sample order: pass c is resolved only after pass c-1 (on whichever stream that ran)
+    auto tryResolve = [&](PassSlot& S) -> int {
+        if (S.chunk != resolved_upto) return TRT_OK;  // an earlier pass is still in flight on the other slot
+        if (resolved_upto > 0) HIPC(hipStreamWaitEvent(S.stream, ev_resolved, 0));  // recorded by the previous resolve, earlier in host order
+        tm.begin(TRT_K_RESOLVE, S.stream);
+        hipLaunchKernelGGL(k_resolve, dim3(std::min<uint32_t>((npix + 255) / 256, 65536u)), dim3(256), 0, S.stream, S.Lacc, d_acc, npix, S.sc_count, (float)p->spp);
+        tm.end(S.stream);
         st.launches[TRT_K_RESOLVE]++;
+        HIPC(hipEventRecord(ev_resolved, S.stream));
+        resolved_upto++;
+        return startPass(S);
+    };
+
+    for (int k = 0; k < slots_used; ++k)
+        if (int e = startPass(slots[k])) return e;
+    for (;;) {
+        bool any = false;
+        for (int k = 0; k < slots_used; ++k)
+            if (slots[k].state == PassSlot::ISSUE) { if (int e = issueFront(slots[k])) return e; }
+        for (int k = 0; k < slots_used; ++k) {
+            PassSlot& S = slots[k];
+            if (S.state == PassSlot::WAIT) { if (int e = completeBounce(S)) return e; }
+            if (S.state == PassSlot::RESOLVE) { if (int e = tryResolve(S)) return e; }
+            any = any || S.state != PassSlot::IDLE;
+        }
+        if (!any) break;
     }
-    tm.begin(TRT_K_RESOLVE);
+    if (resolved_upto != n_chunks) return fail(TRT_EHIP, "internal error: passes left unresolved");
+
+    HIPC(hipStreamWaitEvent(stream, ev_resolved, 0));
+    tm.begin(TRT_K_RESOLVE, stream);
     hipLaunchKernelGGL(k_finalize, dim3(std::min<uint32_t>((npix * 3 + 255) / 256, 65536u)), dim3(256), 0, stream, d_acc, out_dev, npix * 3);
-    tm.end();
+    tm.end(stream);
     HIPC(hipEventRecord(ev_end, stream));
     DeviceStats ds;
     HIPC(hipMemcpyAsync(&ds, d_stats, sizeof(ds), hipMemcpyDeviceToHost, stream));
@@ -568,7 +645,6 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     st.max_bounces = ds.max_depth_hit;
     st.passes = n_chunks;
     st.rows_rendered = rows.size();
-    (void)deepest;
     if (stats_out) *stats_out = st;
     return TRT_OK;
 }
@@ -616,7 +692,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     RaySource src{};
     src.ra = ra;
     src.rb = rb;
-    launchTraceClosest<true, false>(h, nullptr, src, hit, n32, d_stats);
+    launchTraceClosest<true, false>(h, nullptr, (uint32_t*)h->spill.p, src, hit, n32, d_stats);
     HIPC(hipEventRecord(e1, nullptr));
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());
