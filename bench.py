@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--mem-gb", type=float, default=0.0, help="HBM budget for path state (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--overlap", action="store_true", help="TRT_FLAG_OVERLAP: two passes in flight (+4-5 %% Mrays/s; per-kernel timings then overlap)")
     ap.add_argument("--save-png", default=None)
     return ap.parse_args()
 
@@ -88,7 +89,8 @@ def main():
     renderer = T.Renderer(scene, local_rank)
     budget = int(a.mem_gb * (1 << 30))
 
-    p_time = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_TIMING, mem_budget=budget)
+    ov = T.TRT_FLAG_OVERLAP if a.overlap else 0
+    p_time = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_TIMING | ov, mem_budget=budget)
     p_count = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_TIMING | T.TRT_FLAG_COUNT, mem_budget=budget)
     nrows = len(T.rows_selected(p_time))
     out = torch.empty((nrows, a.width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -169,7 +171,7 @@ def main():
             "dtype": "f32", "data": f"scene '{a.scene}' ({WORKLOADS[a.scene]}), counter RNG seed {seed:#x}",
             "config": {"workload": f"{WORKLOADS[a.scene]}, {a.width}x{a.height}, {a.spp} spp", "scene": a.scene, "width": a.width,
                        "height": a.height, "spp": a.spp, "triangles": scene.info["n_triangles"], "bvh_nodes": scene.arrays()["n_nodes"],
-                       "leaf_num": a.leaf if a.leaf is not None else (T.TINY_LEAF if scene.info["n_triangles"] <= 64 else T.DEFAULT_LEAF), "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
+                       "leaf_num": a.leaf if a.leaf is not None else (T.TINY_LEAF if scene.info["n_triangles"] <= 64 else T.DEFAULT_LEAF), "overlap_passes": bool(a.overlap), "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
             "rays_per_step": rays_total // a.steps,
             "rays_rank0": {"camera": st.rays_camera, "shadow": st.rays_shadow, "indirect": st.rays_indirect},
             "device_render_ms_per_step_rank0": round(render_ms / a.steps, 3),

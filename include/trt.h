@@ -135,6 +135,8 @@ typedef struct trt_scene {
 
 #define TRT_FLAG_TIMING 1u   /* per-kernel hipEvent timing into trt_stats */
 #define TRT_FLAG_COUNT 2u    /* count inner-node visits / triangle tests (stats kernels) */
+#define TRT_FLAG_OVERLAP 4u  /* keep two sample passes in flight on two streams (+4-5 % throughput; per-kernel
+                              * timings then include the other pass's kernels, so profiling runs leave it off) */
 
 typedef struct trt_params {
     int32_t width, height;   /* full image size (scene.img_width/height, scene.cpp:13-14) */

@@ -124,22 +124,21 @@ def test_sample_chunking_is_invisible(renderer_factory):
     big, st_big = r.render(T.make_params(96, 96, 24, 3))
     per_path = 2 * 48 + 16 + 16 + 48
     small, st_small = r.render(T.make_params(96, 96, 24, 3, mem_budget=96 * 96 * 5 * per_path))
-    assert st_small.passes > st_big.passes >= 1
+    assert st_big.passes == 1 and st_small.passes == 5
     assert np.array_equal(big, small)
     assert st_big.rays == st_small.rays
 
 
-def test_overlapped_passes_equal_serial_passes(monkeypatch):
-    """Two passes in flight on two streams (the default) vs TRT_SLOTS=1: identical image and counters."""
+def test_overlapped_passes_equal_serial_passes():
+    """TRT_FLAG_OVERLAP (two passes in flight on two streams) vs one pass at a time: identical image and counters."""
     s = get_scene("veach-mis", 128, 72)
-    p = T.make_params(128, 72, 12, 31, flags=T.TRT_FLAG_COUNT)
     out = []
-    for slots in ("2", "1"):
-        monkeypatch.setenv("TRT_SLOTS", slots)
+    for flags in (T.TRT_FLAG_COUNT | T.TRT_FLAG_OVERLAP, T.TRT_FLAG_COUNT):
         r = T.Renderer(s, 0)
-        img, st = r.render(p)
+        img, st = r.render(T.make_params(128, 72, 12, 31, flags=flags))
         r.close()
         out.append((img, st.rays, st.shaded_hits, st.inner_visits[0], st.tri_tests[1]))
+        assert st.passes >= (2 if flags & T.TRT_FLAG_OVERLAP else 1)
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:]
 
 

@@ -71,7 +71,7 @@ struct trt_handle {
     DevBuf arena, spill, small_buf, out_buf, io_buf;
     size_t spill_words_per_slot = 0;
     hipStream_t slot_streams[2] = {nullptr, nullptr};  // one per concurrent pass (trt_render_device)
-    int n_slots = 2;                                   // TRT_SLOTS=1 in the environment disables the overlap
+    int n_slots = 2;                                   // TRT_SLOTS=1 in the environment vetoes TRT_FLAG_OVERLAP
     uint32_t* pinned_counts = nullptr;                 // host-pinned landing zone of the per-bounce queue lengths
     std::vector<hipEvent_t> events;
     ~trt_handle()
@@ -429,7 +429,7 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         HIPC(hipMemGetInfo(&free_b, &total_b));
         budget = std::min<uint64_t>((uint64_t)(free_b + h->arena.bytes) / 2, 32ull << 30);
     }
-    const int n_slots = (p->spp >= 2 && h->n_slots > 1) ? N_SLOTS : 1;
+    const int n_slots = (p->spp >= 2 && (p->flags & TRT_FLAG_OVERLAP) && h->n_slots > 1) ? N_SLOTS : 1;
     uint64_t max_paths = std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull);
     if (max_paths < npix) return fail(TRT_ENOMEM, "mem_budget too small for one sample of every pixel of the tile; render smaller tiles");
     if (n_slots > 1 && max_paths / n_slots >= npix) max_paths /= n_slots;  // each slot gets its share of the budget

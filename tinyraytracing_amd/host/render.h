@@ -19,6 +19,7 @@ struct RenderOpts {
     int max_depth = 0;
     uint64_t mem_budget = 0;
     bool timing = false;
+    bool overlap = true;      // two sample passes in flight (TRT_FLAG_OVERLAP)
 };
 
 // image: img_width*img_height*3 doubles, zero-initialised by the caller like
