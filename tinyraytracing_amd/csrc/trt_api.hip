@@ -66,6 +66,7 @@ struct trt_handle {
     std::vector<void*> scene_allocs;
     std::vector<uint32_t> light_mats;
     uint32_t depth = 0;
+    uint32_t lds_tab[4] = {0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles that k_shade stages in LDS
     int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
     uint32_t tail_n = 32768;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
     DevBuf arena, spill, small_buf, out_buf, io_buf;
@@ -94,7 +95,7 @@ template <class T>
 int upload(trt_handle* h, const T* src, size_t count, const T** dst)
 {
     void* p = nullptr;
-    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 15) & ~(size_t)15;  // readable in whole 16-B words
     HIPC(hipMalloc(&p, bytes));
     h->scene_allocs.push_back(p);
     if (count) HIPC(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
@@ -362,6 +363,16 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     h->sc.light0_area = s->n_lights ? s->lights[0].area : 0.0f;
     h->sc.cam = s->camera;
     for (uint32_t i = 0; i < s->n_lights; ++i) h->light_mats.push_back((uint32_t)s->lights[i].mat);
+    {   // which small tables k_shade copies into LDS: in this order while they fit (uploads are padded to 16 B)
+        const uint32_t want[4] = {(uint32_t)(s->n_materials * sizeof(MaterialDev)), (uint32_t)(s->n_lights * sizeof(LightDev)),
+                                  h->sc.light_cum ? (uint32_t)(s->n_light_tris * sizeof(float)) : 0u, (uint32_t)(s->n_light_tris * sizeof(LightTriDev))};
+        uint32_t used = 0;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t padded = (want[k] + 15u) & ~15u;
+            if (want[k] && used + padded <= TRT_SHADE_LDS_TABLE_BYTES) { h->lds_tab[k] = want[k]; used += padded; }
+        }
+        if (std::getenv("TRT_SHADE_NO_LDS")) h->lds_tab[0] = h->lds_tab[1] = h->lds_tab[2] = h->lds_tab[3] = 0;
+    }
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
     const uint32_t spill_levels = depth > (uint32_t)TRT_LDS_STACK_MAX ? depth - TRT_LDS_STACK_MAX + 1 : 1;
@@ -539,6 +550,10 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         A.s0 = S.s0;
         A.max_depth = p->max_depth;
         A.primary = S.b == 0 ? 1u : 0u;
+        A.lds_mat_bytes = h->lds_tab[0];
+        A.lds_light_bytes = h->lds_tab[1];
+        A.lds_cum_bytes = h->lds_tab[2];
+        A.lds_ltri_bytes = h->lds_tab[3];
         A.stats = d_stats;
         tm.begin(TRT_K_SHADE, S.stream);
         hipLaunchKernelGGL(k_shade, dim3(std::min<uint32_t>((S.n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u)), dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A);

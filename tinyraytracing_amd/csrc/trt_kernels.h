@@ -604,14 +604,36 @@ struct ShadeArgs {
     uint32_t s0;
     int32_t max_depth;
     uint32_t primary;         // bounce 0: entry i is the camera ray of path i (not in HBM); Lacc is initialised here
+    // Small scene tables staged in LDS by every block (byte counts; 0 = leave that table in global memory):
+    // material / light / CDF / light-triangle look-ups then cost an LDS access instead of a dependent
+    // global round trip each — k_shade is bound by exactly that chain of round trips.
+    uint32_t lds_mat_bytes, lds_light_bytes, lds_cum_bytes, lds_ltri_bytes;
     DeviceStats* stats;
 };
+
+constexpr uint32_t TRT_SHADE_LDS_TABLE_BYTES = 24 * 1024;
 
 __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
 {
     __shared__ uint32_t s_cnt[2 * (TRT_SHADE_BLOCK / 64 + 1)];
     __shared__ uint32_t s_shaded, s_anyhit;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[TRT_SHADE_LDS_TABLE_BYTES / 4];
     if (threadIdx.x == 0) { s_shaded = 0; s_anyhit = 0; }
+    {   // stage the tables that fit (16-byte words, coalesced), then point this block's scene view at them
+        uint32_t off = 0;
+        auto stage = [&](const void* src, uint32_t bytes) -> const void* {
+            if (bytes == 0) return src;
+            const f4* g = reinterpret_cast<const f4*>(src);
+            f4* l = reinterpret_cast<f4*>(s_tab + off / 4);
+            for (uint32_t w = threadIdx.x; w < (bytes + 15u) / 16u; w += TRT_SHADE_BLOCK) l[w] = g[w];
+            off += (bytes + 15u) & ~15u;
+            return l;
+        };
+        sc.materials = static_cast<const MaterialDev*>(stage(sc.materials, A.lds_mat_bytes));
+        sc.lights = static_cast<const LightDev*>(stage(sc.lights, A.lds_light_bytes));
+        sc.light_cum = static_cast<const float*>(stage(sc.light_cum, A.lds_cum_bytes));
+        sc.light_tris = static_cast<const LightTriDev*>(stage(sc.light_tris, A.lds_ltri_bytes));
+    }
     __syncthreads();
     int parity = 0;
     uint32_t bounce_depth = 0;
