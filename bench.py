@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--tris", type=int, default=None, help="triangle count of the synthetic scenes")
-    ap.add_argument("--leaf", type=int, default=None, help="triangles per BVH leaf (the reference uses 8); default: 8 for scenes of <= 64 triangles, else 4")
+    ap.add_argument("--leaf", type=int, default=None, help="triangles per BVH leaf (the reference uses 8); default: 8 for scenes of <= 64 triangles, else 2")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=None)
     ap.add_argument("--mem-gb", type=float, default=0.0, help="HBM budget for path state (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -24,9 +24,9 @@ SEED_STAIRCASE = 0x5EED0004
 SEED_BLOB = 0x5EED0005
 
 _BUILDERS = {"sweep": 0, "binned": 1, "auto": 2}
-# Triangles per BVH leaf.  The reference calls buildBVH(..., 8) (main.cpp:76); on the GPU 4 measured faster on every
+# Triangles per BVH leaf.  The reference calls buildBVH(..., 8) (main.cpp:76); on the GPU 2 measured fastest on every
 # scene larger than the Cornell box, and the topology is free: only nearest-hit + tie rules matter.
-DEFAULT_LEAF = 4
+DEFAULT_LEAF = 2
 TINY_LEAF = 8
 
 
@@ -72,7 +72,7 @@ class Scene:
             raise TrtError(f"unknown scene {name!r}")
         if leaf_num is None:
             # tiny scenes are walked wave-uniformly (every node, every triangle: trt_kernels.h IMPL 0), where fewer,
-            # fuller leaves are cheaper; everything else is traversed per ray, where 4 measured best
+            # fuller leaves are cheaper; everything else is traversed per ray, where 2 measured best
             leaf_num = TINY_LEAF if s.info["n_triangles"] <= 64 else DEFAULT_LEAF
         s.build_bvh(leaf_num, builder)
         return s

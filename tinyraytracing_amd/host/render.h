@@ -14,7 +14,7 @@ struct RenderOpts {
     int spp = 256;            // SAMPLE (main.cpp:13)
     uint32_t seed = 0x5EED0001u;
     int device = 0;
-    int leaf_num = 4;         // the reference calls buildBVH(..., 8) (main.cpp:76); 4 is faster on the GPU
+    int leaf_num = 2;         // the reference calls buildBVH(..., 8) (main.cpp:76); 2 is fastest on the GPU
     BvhBuilder builder = BVH_AUTO;
     int max_depth = 0;
     uint64_t mem_budget = 0;
