@@ -220,6 +220,19 @@ def test_config3_soup_tile_vs_oracle(renderer_factory):
         assert st.rays == ost.rays
 
 
+def test_config4_staircase_tile_at_1024spp_vs_oracle(renderer_factory):
+    """Config 4 (largest cg22 scene, 1920x1080, 1024 spp): tiles of the full-size frame against the oracle.
+    6 lights (Q3 CDF quirk), 3 textures, glass (Fresnel / TIR), Phong lobes up to Ns = 1000."""
+    s = get_scene("staircase", 1920, 1080)
+    r = renderer_factory(s)
+    for (x0, y0) in ((900, 500), (300, 900)):
+        pt = T.make_params(1920, 1080, 1024, T.SEED_STAIRCASE, tile=(x0, y0, x0 + 8, y0 + 6))
+        img, st = r.render(pt)
+        ref, ost = O.render(s.flat, pt)
+        assert_same_image(img, ref, f"staircase tile {x0},{y0}")
+        assert st.rays == ost.rays and st.max_bounces == ost.max_bounces
+
+
 # ------------------------------------------------------------------ edge cases and error behaviour
 def test_empty_and_single_triangle_scenes(tmp_path):
     SU.write_scene(tmp_path, "empty", "v 0 0 0\n", SU.MTL_BASIC, w=16, h=16)

@@ -20,9 +20,6 @@
 #ifndef TRT_PREFETCH
 #define TRT_PREFETCH 1
 #endif
-#ifndef TRT_BOX_FMA
-#define TRT_BOX_FMA 0
-#endif
 
 namespace trtd {
 
@@ -213,16 +210,8 @@ TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& u
 // d == 0 and the origin exactly on the padded plane).
 TRT_HD inline bool boxTest(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float& entry)
 {
-#if TRT_BOX_FMA
-    // experiment: (B - o) * inv as fma(B, inv, -(o * inv)) — one instruction per plane instead of two.  Rounds
-    // differently from the reference form, which can only move a ray that grazes a padded box by an ulp.
-    const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
-    const float inx = fmaf(hix, inv.x, nox), iny = fmaf(hiy, inv.y, noy), inz = fmaf(hiz, inv.z, noz);
-    const float outx = fmaf(lox, inv.x, nox), outy = fmaf(loy, inv.y, noy), outz = fmaf(loz, inv.z, noz);
-#else
     const float inx = (hix - o.x) * inv.x, iny = (hiy - o.y) * inv.y, inz = (hiz - o.z) * inv.z;
     const float outx = (lox - o.x) * inv.x, outy = (loy - o.y) * inv.y, outz = (loz - o.z) * inv.z;
-#endif
     const float t1 = fminf(fmaxf(inx, outx), fminf(fmaxf(iny, outy), fmaxf(inz, outz)));
     const float t0 = fmaxf(fminf(inx, outx), fmaxf(fminf(iny, outy), fminf(inz, outz)));
     entry = t0;
