@@ -15,7 +15,7 @@ CXXFLAGS := -O2 -g0 -std=c++17 -fPIC -Wall -Wextra $(CPU_FP) -Iinclude -I$(PKG)/
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
             -Wall -Wextra -Wno-unused-parameter -Iinclude -I$(PKG)/csrc
 
-HOST_SRC := $(PKG)/host/scene.cpp $(PKG)/host/bvh.cpp $(PKG)/host/synth.cpp $(PKG)/host/image_out.cpp $(PKG)/host/capi.cpp
+HOST_SRC := $(PKG)/host/scene.cpp $(PKG)/host/bvh.cpp $(PKG)/host/synth.cpp $(PKG)/host/image_out.cpp $(PKG)/host/jpeg.cpp $(PKG)/host/capi.cpp
 HOST_HDR := $(wildcard $(PKG)/host/*.h) include/trt.h include/trt_host.h include/trt_prims.h
 HIP_SRC := $(PKG)/csrc/trt_api.hip
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h

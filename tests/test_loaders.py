@@ -60,15 +60,52 @@ def test_staircase_counts_lights_textures():
     assert f.materials[glass].Ni == 1.5 and np.allclose(tuple(f.materials[glass].Tr), (0.8, 1.0, 0.95))
 
 
-def test_texture_sidecar_matches_pil_decode():
-    s = get_scene("staircase", 64, 36)
-    f = s.flat.contents
-    for k in range(3):
-        tx = f.textures[k]
-        if (tx.width, tx.height) == (512, 512):
-            ref = np.asarray(Image.open(os.path.join(T.SCENES_DIR, "staircase", "textures", "Wallpaper.jpg")).convert("RGB"))
-            got = np.ctypeslib.as_array(tx.rgb, shape=(tx.height, tx.width, 3))
-            assert np.array_equal(ref, got)
+def _decode(path):
+    lib = T._abi.load_host()
+    w, h = C.c_int(), C.c_int()
+    assert lib.trth_decode_jpeg(os.fsencode(path), C.byref(w), C.byref(h), None, 0) == 0, lib.trth_last_error()
+    buf = np.empty((h.value, w.value, 3), np.uint8)
+    assert lib.trth_decode_jpeg(os.fsencode(path), C.byref(w), C.byref(h), buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size) == 0
+    return buf
+
+
+def test_jpeg_decoder_is_bit_identical_to_libjpeg_on_the_shipped_textures():
+    """Material::readinMap (material.cpp:3-11: cv::imread): host/jpeg.cpp must yield libjpeg's texels."""
+    for name in ("Tiles.jpg", "Wallpaper.jpg", "wood5.jpg"):      # 4:4:4, 4:2:0, 4:2:0
+        path = os.path.join(T.SCENES_DIR, "staircase", "textures", name)
+        assert np.array_equal(_decode(path), np.asarray(Image.open(path).convert("RGB"))), name
+    # and that is what ends up in the flat scene
+    f = get_scene("staircase", 64, 36).flat.contents
+    tx = [f.textures[k] for k in range(3) if (f.textures[k].width, f.textures[k].height) == (512, 512)][0]
+    ref = np.asarray(Image.open(os.path.join(T.SCENES_DIR, "staircase", "textures", "Wallpaper.jpg")).convert("RGB"))
+    assert np.array_equal(np.ctypeslib.as_array(tx.rgb, shape=(512, 512, 3)), ref)
+
+
+@pytest.mark.parametrize("size", [(64, 48), (37, 53), (1, 1), (17, 8), (250, 3)])
+@pytest.mark.parametrize("subsampling", [0, 1, 2])                 # 4:4:4, 4:2:2 (h2v1), 4:2:0 (h2v2)
+def test_jpeg_decoder_on_generated_images(tmp_path, size, subsampling):
+    rng = np.random.default_rng(size[0] * 31 + subsampling)
+    w, h = size
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 5 + yy * 3) % 256, (xx * yy) % 256, rng.integers(0, 256, (h, w))], -1).astype(np.uint8)
+    path = str(tmp_path / "t.jpg")
+    Image.fromarray(img).save(path, quality=85, subsampling=subsampling)
+    assert np.array_equal(_decode(path), np.asarray(Image.open(path).convert("RGB")))
+    gray = str(tmp_path / "g.jpg")
+    Image.fromarray(img[:, :, 2]).save(gray, quality=70)
+    assert np.array_equal(_decode(gray), np.asarray(Image.open(gray).convert("RGB")))
+
+
+def test_jpeg_decoder_rejects_what_it_does_not_handle(tmp_path):
+    lib = T._abi.load_host()
+    w, h = C.c_int(), C.c_int()
+    prog = str(tmp_path / "p.jpg")
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(prog, progressive=True)
+    assert lib.trth_decode_jpeg(os.fsencode(prog), C.byref(w), C.byref(h), None, 0) != 0      # progressive: sidecar route
+    bad = str(tmp_path / "x.jpg")
+    open(bad, "wb").write(b"\xff\xd8\xff\xe0garbage")
+    assert lib.trth_decode_jpeg(os.fsencode(bad), C.byref(w), C.byref(h), None, 0) != 0
+    assert lib.trth_decode_jpeg(os.fsencode(str(tmp_path / "missing.jpg")), C.byref(w), C.byref(h), None, 0) != 0
 
 
 def test_camera_setup_and_resolution_override():

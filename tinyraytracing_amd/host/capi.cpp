@@ -8,6 +8,8 @@
 #include "scene.h"
 #include "trt_host.h"
 
+namespace trt { bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height); }
+
 struct trth_scene {
     trt::Scene scene;
     trt::FlatBVH bvh;
@@ -117,6 +119,21 @@ const char* trth_scene_material_name(const trth_scene* s, uint32_t i)
 }
 
 void trth_scene_free(trth_scene* s) { delete s; }
+
+int trth_decode_jpeg(const char* path, int* width, int* height, uint8_t* rgb, uint64_t rgb_capacity)
+{
+    if (!path || !width || !height) return fail("trth_decode_jpeg: null argument");
+    std::vector<uint8_t> px;
+    int w = 0, h = 0;
+    if (!trt::decodeJPEG(path, px, w, h)) return fail("trth_decode_jpeg: not a baseline JPEG this decoder handles");
+    *width = w;
+    *height = h;
+    if (rgb) {
+        if (rgb_capacity < px.size()) return fail("trth_decode_jpeg: buffer too small");
+        std::memcpy(rgb, px.data(), px.size());
+    }
+    return 0;
+}
 
 int trth_abi_sizes(int64_t out[12])
 {

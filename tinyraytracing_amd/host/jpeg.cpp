@@ -1,0 +1,414 @@
+// jpeg.cpp — baseline JPEG decoder for map_Kd textures.
+//
+// The reference loads textures with cv::imread (material.cpp:6), i.e. libjpeg's default decode.  OpenCV and
+// libjpeg headers are not available to this build, so the decode is restated here with libjpeg's own
+// arithmetic, which makes the texels bit-identical to what the reference sees:
+//   * Huffman / dequantisation per ITU T.81 (baseline, 8-bit, SOF0; restart intervals supported),
+//   * the "islow" integer inverse DCT (13-bit constants, 2 extra bits kept between the passes),
+//   * "fancy" (triangle-filter) chroma upsampling for 2x horizontal and/or 2x vertical subsampling,
+//   * YCbCr -> RGB with 16-bit fixed-point tables.
+// tests/test_loaders.py checks the output against PIL's (libjpeg-turbo's) decode of the shipped textures.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace trt {
+namespace {
+
+struct Huff {
+    uint8_t bits[17] = {0};
+    uint8_t vals[256] = {0};
+    int mincode[17], maxcode[18], valptr[17];
+    bool present = false;
+    void build()
+    {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            valptr[l] = k;
+            mincode[l] = code;
+            code += bits[l];
+            k += bits[l];
+            maxcode[l] = bits[l] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+    }
+};
+
+struct Component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int width = 0, height = 0;    // true downsampled size
+    int stride = 0, rows = 0;     // allocated (multiple of 8 * blocks per MCU)
+    std::vector<uint8_t> plane;   // decoded samples
+    int pred = 0;
+};
+
+struct BitReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint32_t acc = 0;
+    int nbits = 0;
+    bool hit_marker = false;
+    void fill()
+    {
+        while (nbits <= 24) {
+            int byte = 0;
+            if (!hit_marker && p < end) {
+                byte = *p++;
+                if (byte == 0xFF) {
+                    const int b2 = p < end ? *p : 0;
+                    if (b2 == 0) ++p;                 // stuffed zero
+                    else { hit_marker = true; --p; byte = 0; }  // a marker: feed zeros from here on
+                }
+            }
+            acc |= (uint32_t)byte << (24 - nbits);
+            nbits += 8;
+        }
+    }
+    int get(int n)
+    {
+        if (n == 0) return 0;
+        if (nbits < n) fill();
+        const int v = (int)(acc >> (32 - n));
+        acc <<= n;
+        nbits -= n;
+        return v;
+    }
+    void reset() { acc = 0; nbits = 0; hit_marker = false; }
+};
+
+inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+
+int decodeSymbol(BitReader& br, const Huff& h)
+{
+    int code = 0;
+    for (int l = 1; l <= 16; ++l) {
+        code = (code << 1) | br.get(1);
+        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    return -1;
+}
+
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+inline uint8_t clampSample(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// libjpeg jidctint.c (JDCT_ISLOW): Loeffler-Ligtenberg-Moschytz, CONST_BITS = 13, PASS1_BITS = 2.
+void idctIslow(const int32_t* coef, uint8_t* out, int stride)
+{
+    constexpr int CB = 13, P1 = 2;
+    constexpr int32_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137, F1961 = 16069,
+                      F2053 = 16819, F2562 = 20995, F3072 = 25172;
+    int32_t ws[64];
+    for (int c = 0; c < 8; ++c) {
+        const int32_t* in = coef + c;
+        int32_t z2 = in[16], z3 = in[48];
+        int32_t z1 = (z2 + z3) * F0541;
+        int32_t tmp2 = z1 + z3 * (-F1847);
+        int32_t tmp3 = z1 + z2 * F0765;
+        z2 = in[0];
+        z3 = in[32];
+        int32_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
+        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = in[56]; tmp1 = in[40]; tmp2 = in[24]; tmp3 = in[8];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+        int32_t z4 = tmp1 + tmp3;
+        const int32_t z5 = (z3 + z4) * F1175;
+        tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+        z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+        z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        ws[c] = descale(tmp10 + tmp3, CB - P1);       ws[56 + c] = descale(tmp10 - tmp3, CB - P1);
+        ws[8 + c] = descale(tmp11 + tmp2, CB - P1);   ws[48 + c] = descale(tmp11 - tmp2, CB - P1);
+        ws[16 + c] = descale(tmp12 + tmp1, CB - P1);  ws[40 + c] = descale(tmp12 - tmp1, CB - P1);
+        ws[24 + c] = descale(tmp13 + tmp0, CB - P1);  ws[32 + c] = descale(tmp13 - tmp0, CB - P1);
+    }
+    for (int r = 0; r < 8; ++r) {
+        const int32_t* w = ws + r * 8;
+        uint8_t* o = out + r * stride;
+        int32_t z2 = w[2], z3 = w[6];
+        int32_t z1 = (z2 + z3) * F0541;
+        int32_t tmp2 = z1 + z3 * (-F1847);
+        int32_t tmp3 = z1 + z2 * F0765;
+        int32_t tmp0 = (w[0] + w[4]) * (1 << CB), tmp1 = (w[0] - w[4]) * (1 << CB);
+        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+        int32_t z4 = tmp1 + tmp3;
+        const int32_t z5 = (z3 + z4) * F1175;
+        tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+        z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+        z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        constexpr int S = CB + P1 + 3;
+        o[0] = clampSample(descale(tmp10 + tmp3, S) + 128); o[7] = clampSample(descale(tmp10 - tmp3, S) + 128);
+        o[1] = clampSample(descale(tmp11 + tmp2, S) + 128); o[6] = clampSample(descale(tmp11 - tmp2, S) + 128);
+        o[2] = clampSample(descale(tmp12 + tmp1, S) + 128); o[5] = clampSample(descale(tmp12 - tmp1, S) + 128);
+        o[3] = clampSample(descale(tmp13 + tmp0, S) + 128); o[4] = clampSample(descale(tmp13 - tmp0, S) + 128);
+    }
+}
+
+// libjpeg jdsample.c "fancy" upsampling.  `in` has true size cw x ch; result is (cw*hs) x (ch*vs), cropped by the caller.
+void upsampleFancy(const Component& c, int hs, int vs, std::vector<uint8_t>& out, int& ow, int& oh)
+{
+    const int cw = c.width, ch = c.height;
+    ow = cw * hs;
+    oh = ch * vs;
+    out.resize((size_t)ow * oh);
+    auto row = [&](int y) { return c.plane.data() + (size_t)(y < 0 ? 0 : (y >= ch ? ch - 1 : y)) * c.stride; };
+    if (hs == 1 && vs == 1) {
+        for (int y = 0; y < ch; ++y) std::memcpy(&out[(size_t)y * ow], row(y), (size_t)cw);
+        return;
+    }
+    if (hs == 2 && vs == 1) {  // h2v1_fancy_upsample
+        for (int y = 0; y < ch; ++y) {
+            const uint8_t* in = row(y);
+            uint8_t* o = &out[(size_t)y * ow];
+            if (cw == 1) { o[0] = o[1] = in[0]; continue; }
+            o[0] = in[0];
+            o[1] = (uint8_t)((in[0] * 3 + in[1] + 2) >> 2);
+            for (int x = 1; x < cw - 1; ++x) {
+                const int v = in[x] * 3;
+                o[2 * x] = (uint8_t)((v + in[x - 1] + 1) >> 2);
+                o[2 * x + 1] = (uint8_t)((v + in[x + 1] + 2) >> 2);
+            }
+            o[2 * (cw - 1)] = (uint8_t)((in[cw - 1] * 3 + in[cw - 2] + 1) >> 2);
+            o[2 * (cw - 1) + 1] = in[cw - 1];
+        }
+        return;
+    }
+    if (hs == 1 && vs == 2) {  // h1v2_fancy_upsample
+        for (int y = 0; y < ch; ++y)
+            for (int v = 0; v < 2; ++v) {
+                const uint8_t* in0 = row(y);
+                const uint8_t* in1 = row(v == 0 ? y - 1 : y + 1);
+                uint8_t* o = &out[(size_t)(2 * y + v) * ow];
+                const int bias = v == 0 ? 1 : 2;
+                for (int x = 0; x < cw; ++x) o[x] = (uint8_t)((in0[x] * 3 + in1[x] + bias) >> 2);
+            }
+        return;
+    }
+    // h2v2_fancy_upsample: 9/16, 3/16, 3/16, 1/16 triangle filter
+    for (int y = 0; y < ch; ++y)
+        for (int v = 0; v < 2; ++v) {
+            const uint8_t* in0 = row(y);
+            const uint8_t* in1 = row(v == 0 ? y - 1 : y + 1);
+            uint8_t* o = &out[(size_t)(2 * y + v) * ow];
+            if (cw == 1) {
+                const int s = in0[0] * 3 + in1[0];
+                o[0] = (uint8_t)((s * 4 + 8) >> 4);
+                o[1] = (uint8_t)((s * 4 + 7) >> 4);
+                continue;
+            }
+            int thiscol = in0[0] * 3 + in1[0], nextcol = in0[1] * 3 + in1[1], lastcol;
+            o[0] = (uint8_t)((thiscol * 4 + 8) >> 4);
+            o[1] = (uint8_t)((thiscol * 3 + nextcol + 7) >> 4);
+            lastcol = thiscol;
+            thiscol = nextcol;
+            for (int x = 1; x < cw - 1; ++x) {
+                nextcol = in0[x + 1] * 3 + in1[x + 1];
+                o[2 * x] = (uint8_t)((thiscol * 3 + lastcol + 8) >> 4);
+                o[2 * x + 1] = (uint8_t)((thiscol * 3 + nextcol + 7) >> 4);
+                lastcol = thiscol;
+                thiscol = nextcol;
+            }
+            o[2 * (cw - 1)] = (uint8_t)((thiscol * 3 + lastcol + 8) >> 4);
+            o[2 * (cw - 1) + 1] = (uint8_t)((thiscol * 4 + 7) >> 4);
+        }
+}
+
+}  // namespace
+
+bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height)
+{
+    FILE* fp = std::fopen(path.c_str(), "rb");
+    if (!fp) return false;
+    std::vector<uint8_t> data;
+    {
+        uint8_t buf[65536];
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof(buf), fp)) > 0) data.insert(data.end(), buf, buf + n);
+    }
+    std::fclose(fp);
+    if (data.size() < 4 || data[0] != 0xFF || data[1] != 0xD8) return false;
+
+    uint16_t qt[4][64] = {};
+    Huff dc[4], ac[4];
+    std::vector<Component> comps;
+    int restart_interval = 0;
+    size_t pos = 2;
+    const uint8_t* scan = nullptr;
+    while (pos + 4 <= data.size()) {
+        if (data[pos] != 0xFF) return false;
+        const int marker = data[pos + 1];
+        if (marker == 0xFF) { ++pos; continue; }
+        const size_t len = ((size_t)data[pos + 2] << 8) | data[pos + 3];
+        if (len < 2 || pos + 2 + len > data.size()) return false;
+        const uint8_t* seg = &data[pos + 4];
+        const size_t seglen = len - 2;
+        if (marker == 0xDB) {
+            size_t i = 0;
+            while (i < seglen) {
+                const int pq = seg[i] >> 4, tq = seg[i] & 15;
+                ++i;
+                if (tq > 3 || i + (pq ? 128 : 64) > seglen) return false;
+                for (int k = 0; k < 64; ++k) {
+                    qt[tq][kZigzag[k]] = pq ? (uint16_t)((seg[i] << 8) | seg[i + 1]) : seg[i];
+                    i += pq ? 2 : 1;
+                }
+            }
+        } else if (marker == 0xC0) {
+            if (seglen < 6 || seg[0] != 8) return false;
+            height = (seg[1] << 8) | seg[2];
+            width = (seg[3] << 8) | seg[4];
+            const int nc = seg[5];
+            if ((nc != 1 && nc != 3) || seglen < (size_t)(6 + 3 * nc) || width <= 0 || height <= 0) return false;
+            comps.resize((size_t)nc);
+            for (int c = 0; c < nc; ++c) {
+                comps[c].id = seg[6 + 3 * c];
+                comps[c].h = seg[7 + 3 * c] >> 4;
+                comps[c].v = seg[7 + 3 * c] & 15;
+                comps[c].tq = seg[8 + 3 * c];
+                if (comps[c].tq > 3) return false;
+            }
+        } else if (marker == 0xC1 || marker == 0xC2 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
+            return false;  // extended / progressive / lossless / arithmetic: not baseline
+        } else if (marker == 0xC4) {
+            size_t i = 0;
+            while (i + 17 <= seglen) {
+                const int tc = seg[i] >> 4, th = seg[i] & 15;
+                if (th > 3 || tc > 1) return false;
+                Huff& h = tc ? ac[th] : dc[th];
+                int total = 0;
+                for (int l = 1; l <= 16; ++l) { h.bits[l] = seg[i + l]; total += h.bits[l]; }
+                i += 17;
+                if (total > 256 || i + (size_t)total > seglen) return false;
+                std::memcpy(h.vals, seg + i, (size_t)total);
+                i += (size_t)total;
+                h.build();
+                h.present = true;
+            }
+        } else if (marker == 0xDD) {
+            if (seglen < 2) return false;
+            restart_interval = (seg[0] << 8) | seg[1];
+        } else if (marker == 0xDA) {
+            if (comps.empty() || seglen < 1) return false;
+            const int ns = seg[0];
+            if (ns != (int)comps.size() || seglen < (size_t)(1 + 2 * ns + 3)) return false;  // one interleaved scan
+            for (int k = 0; k < ns; ++k) {
+                const int cid = seg[1 + 2 * k];
+                Component* cp = nullptr;
+                for (auto& c : comps) if (c.id == cid) cp = &c;
+                if (!cp) return false;
+                cp->td = seg[2 + 2 * k] >> 4;
+                cp->ta = seg[2 + 2 * k] & 15;
+                if (cp->td > 3 || cp->ta > 3 || !dc[cp->td].present || !ac[cp->ta].present) return false;
+            }
+            scan = &data[pos + 2 + len];
+            break;
+        }
+        pos += 2 + len;
+    }
+    if (!scan || comps.empty()) return false;
+
+    int hmax = 1, vmax = 1;
+    for (auto& c : comps) {
+        if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2) return false;
+        hmax = c.h > hmax ? c.h : hmax;
+        vmax = c.v > vmax ? c.v : vmax;
+    }
+    for (size_t k = 1; k < comps.size(); ++k)
+        if (comps[k].h != 1 || comps[k].v != 1) return false;  // chroma at full sampling factor is not supported
+    if (comps.size() == 1) { hmax = comps[0].h = 1; vmax = comps[0].v = 1; }
+    const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
+    const int mcux = (width + mcu_w - 1) / mcu_w, mcuy = (height + mcu_h - 1) / mcu_h;
+    for (auto& c : comps) {
+        c.width = (width * c.h + hmax - 1) / hmax;
+        c.height = (height * c.v + vmax - 1) / vmax;
+        c.stride = mcux * c.h * 8;
+        c.rows = mcuy * c.v * 8;
+        c.plane.assign((size_t)c.stride * c.rows, 0);
+        c.pred = 0;
+    }
+
+    BitReader br{scan, data.data() + data.size()};
+    int32_t block[64];
+    int restarts_left = restart_interval;
+    for (int my = 0; my < mcuy; ++my)
+        for (int mx = 0; mx < mcux; ++mx) {
+            if (restart_interval && restarts_left == 0) {
+                // skip to the RSTn marker, reset predictors
+                const uint8_t* q = br.p;
+                while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+                if (q + 1 >= br.end) return false;
+                br.p = q + 2;
+                br.reset();
+                for (auto& c : comps) c.pred = 0;
+                restarts_left = restart_interval;
+            }
+            for (auto& c : comps)
+                for (int by = 0; by < c.v; ++by)
+                    for (int bx = 0; bx < c.h; ++bx) {
+                        std::memset(block, 0, sizeof(block));
+                        const int t = decodeSymbol(br, dc[c.td]);
+                        if (t < 0 || t > 11) return false;
+                        const int diff = t ? extend(br.get(t), t) : 0;
+                        c.pred += diff;
+                        block[0] = c.pred * qt[c.tq][0];
+                        for (int k = 1; k < 64;) {
+                            const int rs = decodeSymbol(br, ac[c.ta]);
+                            if (rs < 0) return false;
+                            const int r = rs >> 4, s = rs & 15;
+                            if (s == 0) {
+                                if (r == 15) { k += 16; continue; }
+                                break;
+                            }
+                            k += r;
+                            if (k > 63) return false;
+                            block[kZigzag[k]] = extend(br.get(s), s) * qt[c.tq][kZigzag[k]];
+                            ++k;
+                        }
+                        uint8_t* dst = c.plane.data() + (size_t)((my * c.v + by) * 8) * c.stride + (size_t)(mx * c.h + bx) * 8;
+                        idctIslow(block, dst, c.stride);
+                    }
+            if (restart_interval) --restarts_left;
+        }
+
+    rgb.resize((size_t)width * height * 3);
+    if (comps.size() == 1) {
+        for (int y = 0; y < height; ++y)
+            for (int x = 0; x < width; ++x) {
+                const uint8_t g = comps[0].plane[(size_t)y * comps[0].stride + x];
+                uint8_t* o = &rgb[((size_t)y * width + x) * 3];
+                o[0] = o[1] = o[2] = g;
+            }
+        return true;
+    }
+    std::vector<uint8_t> up[3];
+    int uw[3], uh[3];
+    for (int k = 0; k < 3; ++k) upsampleFancy(comps[k], hmax / comps[k].h, vmax / comps[k].v, up[k], uw[k], uh[k]);
+    // jdcolor.c ycc_rgb_convert: 16-bit fixed point tables
+    int cr_r[256], cb_b[256], cr_g[256], cb_g[256];
+    for (int i = 0; i < 256; ++i) {
+        const int x = i - 128;
+        cr_r[i] = (int)((91881 * x + 32768) >> 16);    // FIX(1.40200)
+        cb_b[i] = (int)((116130 * x + 32768) >> 16);   // FIX(1.77200)
+        cr_g[i] = -46802 * x;                           // FIX(0.71414)
+        cb_g[i] = -22554 * x + 32768;                   // FIX(0.34414)
+    }
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const int Y = up[0][(size_t)y * uw[0] + x], cb = up[1][(size_t)y * uw[1] + x], cr = up[2][(size_t)y * uw[2] + x];
+            uint8_t* o = &rgb[((size_t)y * width + x) * 3];
+            o[0] = clampSample(Y + cr_r[cr]);
+            o[1] = clampSample(Y + ((cb_g[cb] + cr_g[cr]) >> 16));
+            o[2] = clampSample(Y + cb_b[cb]);
+        }
+    return true;
+}
+
+}  // namespace trt

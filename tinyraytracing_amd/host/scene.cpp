@@ -101,16 +101,19 @@ static bool readPPM(const std::string& path, std::vector<uint8_t>& rgb, int& w, 
     return ok;
 }
 
+bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height);  // jpeg.cpp
+
 bool Material::readinMap()
 {
-    // material.cpp:3-11 decodes with cv::imread.  OpenCV/libjpeg are not
-    // available: textures are read from binary PPM, either the file named by
-    // map_Kd itself or the pre-decoded sidecar "<map_Kd>.ppm" (made by
-    // tools/decode_textures.py with the same libjpeg decode the reference gets
-    // through OpenCV).
+    // material.cpp:3-11 decodes with cv::imread.  OpenCV/libjpeg are not available: binary PPM is read
+    // directly, baseline JPEG through host/jpeg.cpp (libjpeg's integer IDCT / fancy upsampling / colour
+    // tables restated, so the texels are the ones cv::imread yields), and as a last resort the pre-decoded
+    // sidecar "<map_Kd>.ppm" written by tools/decode_textures.py (progressive or CMYK JPEGs, PNG, ...).
     img.clear();
     map_width = map_height = 0;
     if (readPPM(map_Kd, img, map_width, map_height)) return true;
+    if (decodeJPEG(map_Kd, img, map_width, map_height)) return true;
+    img.clear();
     if (readPPM(map_Kd + ".ppm", img, map_width, map_height)) return true;
     std::printf("Cannot read file: %s\n", map_Kd.c_str());
     return false;

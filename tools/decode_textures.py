@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Pre-decodes the JPEG textures of scenes/ into binary PPM sidecars (<name>.jpg.ppm).
 
-The reference decodes map_Kd with cv::imread (material.cpp:6), i.e. libjpeg's default
-decoder (integer IDCT, fancy chroma upsampling).  OpenCV and the libjpeg headers are not
-available to the C++ host code, so Material::readinMap() reads these sidecars instead.
-PIL decodes with the same libjpeg(-turbo) defaults.  Run once; the outputs are committed.
+The reference decodes map_Kd with cv::imread (material.cpp:6).  Material::readinMap() decodes
+baseline JPEG itself (host/jpeg.cpp, bit-identical to libjpeg); for anything else (progressive or
+CMYK JPEG, PNG, ...) it falls back to a "<file>.ppm" sidecar, which this script writes with PIL.
+The shipped staircase textures are baseline JPEGs and need no sidecar.
 """
 import glob
 import os
