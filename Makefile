@@ -35,14 +35,14 @@ tests/hostsim/libhostsim.so: tests/hostsim/hostsim.cpp $(HIP_HDR)
 
 $(OUT)/libtrt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(OUT)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC)
+	$(CXX) $(CXXFLAGS) -fopenmp -shared -o $@ $(HOST_SRC)
 
 $(OUT)/libtrt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
 $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so
-	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -fopenmp -Wl,-rpath,'$$ORIGIN'
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options

@@ -38,8 +38,6 @@ struct Builder {
     std::vector<uint32_t>& idx;
     int leaf_num;
     BvhBuilder kind;
-    std::vector<trt_bvh_node> nodes;
-    uint32_t max_depth = 0;
     std::vector<float> scratch_area;  // suffix areas for the sweep
 
     Builder(const std::vector<Prim>& p, std::vector<uint32_t>& i, int leaf, BvhBuilder k) : prims(p), idx(i), leaf_num(leaf), kind(k) {}
@@ -150,31 +148,68 @@ struct Builder {
         return mid_out > lo && mid_out < hi;
     }
 
-    // Returns the child reference of the subtree over idx[lo,hi).
-    uint32_t build(size_t lo, size_t hi, uint32_t depth)
+    // Chooses the split of idx[lo,hi) (reordering that range) and returns its position.
+    size_t split(size_t lo, size_t hi, uint32_t depth)
     {
         const size_t n = hi - lo;
-        if (n <= (size_t)leaf_num) {
-            if (depth > max_depth) max_depth = depth;
-            return TRT_MAKE_LEAF(lo, n);
-        }
         size_t mid = lo + n / 2;
-        bool use_sweep = kind == BVH_SWEEP_SAH || (kind == BVH_AUTO && n <= 65536);
+        const bool use_sweep = kind == BVH_SWEEP_SAH || (kind == BVH_AUTO && n <= 65536);
         bool ok = false;
         if (depth < 56) {
             if (use_sweep) { int axis; ok = sweepSplit(lo, hi, axis, mid); }
             else ok = binnedSplit(lo, hi, mid);
         }
-        if (!ok) {
-            // degenerate input (coincident centroids) or a runaway depth: median by index
-            mid = lo + n / 2;
+        if (!ok) mid = lo + n / 2;  // degenerate input (coincident centroids) or a runaway depth: median by index
+        return mid;
+    }
+
+    // Builds the subtree over idx[lo,hi) into `out` (appending, parents before children) and returns its
+    // child reference; inner references are absolute indices into `out`.
+    uint32_t build(size_t lo, size_t hi, uint32_t depth, std::vector<trt_bvh_node>& out, uint32_t& deepest)
+    {
+        const size_t n = hi - lo;
+        if (n <= (size_t)leaf_num) {
+            if (depth > deepest) deepest = depth;
+            return TRT_MAKE_LEAF(lo, n);
         }
-        const uint32_t me = (uint32_t)nodes.size();
-        nodes.emplace_back();
+        const size_t mid = split(lo, hi, depth);
+        const uint32_t me = (uint32_t)out.size();
+        out.emplace_back();
         const Box b0 = bounds(lo, mid), b1 = bounds(mid, hi);
-        const uint32_t c0 = build(lo, mid, depth + 1);
-        const uint32_t c1 = build(mid, hi, depth + 1);
-        trt_bvh_node& nd = nodes[me];
+        uint32_t c0, c1;
+        if (n >= PARALLEL_MIN) {
+            // big subtrees: the two halves are independent -> OpenMP tasks, each into its own node vector
+            // (own scratch too), spliced back in pre-order with their inner references shifted
+            std::vector<trt_bvh_node> left, right;
+            uint32_t dl = 0, dr = 0, rl = 0, rr = 0;
+#pragma omp task shared(left, dl, rl) if (n >= PARALLEL_MIN)
+            {
+                Builder sub(prims, idx, leaf_num, kind);
+                rl = sub.build(lo, mid, depth + 1, left, dl);
+            }
+#pragma omp task shared(right, dr, rr) if (n >= PARALLEL_MIN)
+            {
+                Builder sub(prims, idx, leaf_num, kind);
+                rr = sub.build(mid, hi, depth + 1, right, dr);
+            }
+#pragma omp taskwait
+            auto splice = [&](std::vector<trt_bvh_node>& sub, uint32_t ref) -> uint32_t {
+                const uint32_t off = (uint32_t)out.size();
+                for (trt_bvh_node& nd : sub) {
+                    if (!(nd.child0 & TRT_LEAF_BIT)) nd.child0 += off;
+                    if (!(nd.child1 & TRT_LEAF_BIT)) nd.child1 += off;
+                }
+                out.insert(out.end(), sub.begin(), sub.end());
+                return (ref & TRT_LEAF_BIT) ? ref : ref + off;
+            };
+            c0 = splice(left, rl);
+            c1 = splice(right, rr);
+            deepest = std::max(deepest, std::max(dl, dr));
+        } else {
+            c0 = build(lo, mid, depth + 1, out, deepest);
+            c1 = build(mid, hi, depth + 1, out, deepest);
+        }
+        trt_bvh_node& nd = out[me];
         storeBox(nd.lo0, nd.hi0, b0);
         storeBox(nd.lo1, nd.hi1, b1);
         nd.child0 = c0;
@@ -182,6 +217,7 @@ struct Builder {
         nd.reserved[0] = nd.reserved[1] = 0;
         return me;
     }
+    static constexpr size_t PARALLEL_MIN = 200000;
 };
 
 }  // namespace
@@ -203,7 +239,6 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
     std::iota(idx.begin(), idx.end(), 0u);
 
     Builder b(prims, idx, leaf_num, builder);
-    b.nodes.reserve(n / (size_t)std::max(1, leaf_num / 2) + 4);
     FlatBVH out;
     if (n <= (size_t)leaf_num) {
         // A scene that fits one leaf still gets a root node: child0 = all
@@ -220,16 +255,19 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
         out.depth = 1;
         return out;
     }
-    const uint32_t root = b.build(0, n, 0);
+    uint32_t root = 0, deepest = 0;
+    out.nodes.reserve(n / (size_t)std::max(1, leaf_num / 2) + 4);
+#pragma omp parallel
+#pragma omp single
+    root = b.build(0, n, 0, out.nodes, deepest);
     if (root != 0) throw std::runtime_error("buildBVH: internal error (root index)");
-    out.depth = b.max_depth;
+    out.depth = deepest;
 
     // reorder the triangles into leaf order (the reference's in-place sorts)
     std::vector<Triangle> sorted;
     sorted.reserve(n);
     for (size_t i = 0; i < n; ++i) sorted.push_back(std::move(triangles[idx[i]]));
     triangles.swap(sorted);
-    out.nodes.swap(b.nodes);
     return out;
 }
 

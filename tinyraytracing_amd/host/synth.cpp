@@ -125,22 +125,29 @@ void makeBlobScene(Scene& scene, uint32_t seed, uint64_t n_min, int width, int h
         const float a = (float)(m - i - j) / (float)m, b = (float)i / (float)m, c = (float)j / (float)m;
         return normalize(iv[f[0]] * a + iv[f[1]] * b + iv[f[2]] * c);
     };
-    scene.triangles.reserve(scene.triangles.size() + 20ull * m * m);
-    auto emit = [&](vec3 n0, vec3 n1, vec3 n2) {
-        Triangle t;
+    // face f, row i, column j -> triangle slot f*m*m + i*(2m-i) + 2j (+1 for the inverted one): every slot is
+    // written exactly once, so the rows can be generated in parallel and the order never depends on the threads
+    const size_t base = scene.triangles.size();
+    scene.triangles.resize(base + 20ull * m * m);
+    auto emit = [&](size_t slot, vec3 n0, vec3 n1, vec3 n2) {
+        Triangle& t = scene.triangles[base + slot];
         t.v[0] = point(n0); t.v[1] = point(n1); t.v[2] = point(n2);
         t.vn[0] = smoothNormal(n0); t.vn[1] = smoothNormal(n1); t.vn[2] = smoothNormal(n2);
         t.normal = normalize(cross(t.v[1] - t.v[0], t.v[2] - t.v[0]));
         t.center = (t.v[0] + t.v[1] + t.v[2]) / 3.0f;
         t.mtl_id = mat;
-        scene.triangles.push_back(std::move(t));
     };
-    for (int f = 0; f < 20; ++f)
-        for (uint64_t i = 0; i < m; ++i)
-            for (uint64_t j = 0; i + j < m; ++j) {
-                emit(corner(faces[f], i, j), corner(faces[f], i + 1, j), corner(faces[f], i, j + 1));
-                if (i + j + 1 < m) emit(corner(faces[f], i + 1, j), corner(faces[f], i + 1, j + 1), corner(faces[f], i, j + 1));
-            }
+    const long long rows_total = 20ll * (long long)m;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long long fr = 0; fr < rows_total; ++fr) {
+        const int f = (int)(fr / (long long)m);
+        const uint64_t i = (uint64_t)(fr % (long long)m);
+        const size_t row0 = (size_t)f * m * m + (size_t)(i * (2 * m - i));
+        for (uint64_t j = 0; i + j < m; ++j) {
+            emit(row0 + 2 * j, corner(faces[f], i, j), corner(faces[f], i + 1, j), corner(faces[f], i, j + 1));
+            if (i + j + 1 < m) emit(row0 + 2 * j + 1, corner(faces[f], i + 1, j), corner(faces[f], i + 1, j + 1), corner(faces[f], i, j + 1));
+        }
+    }
 }
 
 }  // namespace trt
