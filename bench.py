@@ -49,11 +49,13 @@ def parse():
 
 
 def algorithmic_bytes(st):
-    """SURVEY.md §8d canonical sizes: inner-node visit 64 B, triangle test 48 B, ray record 32 B read,
-    hit record 16 B written, shaded hit 64 B, generated ray 32 B written, framebuffer 12 B / pixel."""
+    """SURVEY.md §8d canonical sizes: 32 B per child box + reference of a visited inner node (64 B for a
+    two-child node, 128 B for a four-child one: trt_stats.inner_node_bytes), triangle test 48 B, ray record
+    32 B read, hit record 16 B written, shaded hit 64 B, generated ray 32 B written, framebuffer 12 B / pixel."""
     closest_rays = st.rays_camera + st.rays_indirect
-    b_closest = 64 * st.inner_visits[0] + 48 * st.tri_tests[0] + (32 + 16) * closest_rays
-    b_shadow = 64 * st.inner_visits[1] + 48 * st.tri_tests[1] + (32 + 16) * st.rays_shadow
+    nb = st.inner_node_bytes or 64
+    b_closest = nb * st.inner_visits[0] + 48 * st.tri_tests[0] + (32 + 16) * closest_rays
+    b_shadow = nb * st.inner_visits[1] + 48 * st.tri_tests[1] + (32 + 16) * st.rays_shadow
     b_shade = 64 * st.shaded_hits + 32 * (st.rays_shadow + st.rays_indirect)
     b_gen = 32 * st.rays_camera
     return {"trace_closest": b_closest, "trace_shadow": b_shadow, "shade": b_shade, "gen_primary": b_gen}

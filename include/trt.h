@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TRT_ABI_VERSION 1
+#define TRT_ABI_VERSION 2
 
 /* error codes */
 #define TRT_OK 0
@@ -168,7 +168,8 @@ typedef struct trt_stats {
     uint64_t rays_shadow;       /* NEE closest-hit rays traced (pathTracing.cpp:54) */
     uint64_t rays_indirect;     /* valid extension rays traced (pathTracing.cpp:81, INVALID excluded) */
     uint64_t shaded_hits;       /* path vertices that reached shade() */
-    uint64_t inner_visits[2];   /* [closest, shadow] inner nodes whose two child boxes were tested (TRT_FLAG_COUNT) */
+    uint64_t inner_visits[2];   /* [closest, shadow] inner nodes visited = all child boxes fetched and tested (TRT_FLAG_COUNT);
+                                 * inner_node_bytes says how much one visit reads */
     uint64_t tri_tests[2];      /* [closest, shadow] triangle tests (TRT_FLAG_COUNT) */
     uint64_t wave_steps[2];     /* wave-level iterations of the traversal kernels' [inner-node, leaf] phases (TRT_FLAG_COUNT):
                                  * inner_visits / (64 * wave_steps[0]) is the SIMD utilisation of the inner phase */
@@ -178,6 +179,9 @@ typedef struct trt_stats {
     uint32_t passes;            /* sample chunks the render was split into */
     uint32_t max_bounces;       /* deepest path vertex index reached */
     uint64_t rows_rendered;     /* rows in the packed output */
+    uint32_t inner_node_bytes;  /* bytes one inner-node visit fetches: 64 (the caller's BVH2 node: two boxes + refs, tiny scenes)
+                                 * or 128 (its 4-wide collapse: four boxes + refs) */
+    uint32_t reserved;
 } trt_stats;
 
 typedef struct trt_handle trt_handle;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "trt_path.h"
+#include "trt_wide.h"
 
 using namespace trtd;
 
@@ -27,6 +28,7 @@ struct HostScene {
     std::vector<float> cum;
     std::vector<LightDev> lights;
     std::vector<LightTriDev> ltris;
+    WideTree wide;
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
     {
@@ -54,6 +56,9 @@ struct HostScene {
             tex_bytes.insert(tex_bytes.end(), s->textures[i].rgb, s->textures[i].rgb + nb);
         }
         sc.nodes = s->nodes;
+        wide = collapseBvh(s->nodes, s->n_nodes);
+        sc.wnodes = wide.nodes.data();
+        sc.n_wnodes = (uint32_t)wide.nodes.size();
         sc.tri_isect = isect.data();
         sc.tri_shade = shade.data();
         sc.materials = mats.data();

@@ -29,3 +29,35 @@ def random_rays(n, lo, hi, seed=11):
 def scene_bounds(scene):
     v = scene.arrays()["tri_v"].reshape(-1, 3)
     return v.min(0), v.max(0)
+
+
+def adversarial_rays(scene, n, seed=31):
+    """Rays that stress the slab test's corner cases: direction components that are exactly 0 (1/d = inf,
+    0 * inf = NaN when the origin sits on a box plane), origins exactly on vertex coordinates (the planes
+    of the tight boxes) and on wall planes, and directions along the axes."""
+    rng = np.random.default_rng(seed)
+    v = scene.arrays()["tri_v"].reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    org = (rng.random((n, 3)) * (hi - lo) + lo).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    k = np.arange(n)
+    # a third: origin coordinates copied from random vertices (exactly on box planes)
+    pick = v[rng.integers(0, len(v), n)]
+    on = (k % 3) == 0
+    ax = rng.integers(0, 3, n)
+    org[on, ax[on]] = pick[on, ax[on]]
+    # zero out one or two direction components, some with -0.0
+    z1 = (k % 2) == 0
+    a1 = rng.integers(0, 3, n)
+    d[z1, a1[z1]] = np.where(rng.random(z1.sum()) < 0.5, np.float32(0.0), np.float32(-0.0))
+    z2 = (k % 5) == 0
+    a2 = (a1 + 1) % 3
+    d[z2, a2[z2]] = 0.0
+    # the zeroed axis of an on-plane origin: make them coincide for half of those
+    both = on & z1 & (rng.random(n) < 0.5)
+    org[both, a1[both]] = pick[both, a1[both]]
+    bad = np.abs(d).sum(1) == 0
+    d[bad] = (1.0, 0.0, 0.0)
+    return org, d

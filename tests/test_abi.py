@@ -52,7 +52,7 @@ def test_ctypes_mirror_matches_c_struct_sizes():
 
 def test_abi_version_and_rows_selected_without_gpu():
     lib = _abi.load_hip()
-    assert lib.trt_abi_version() == 1
+    assert lib.trt_abi_version() == _abi.TRT_ABI_VERSION
     import tinyraytracing_amd as T
     p = T.make_params(64, 37, 1, 0, rows=(8, 3, 1))
     assert lib.trt_rows_selected(C.byref(p)) == len(T.rows_selected(p))

@@ -54,6 +54,18 @@ def test_trace_matches_oracle_on_incoherent_rays(name, n, renderer_factory):
     assert [st.inner_visits[0], st.tri_tests[0]] in (cnt, [ost.inner_visits[0], ost.tri_tests[0]])
 
 
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_trace_degenerate_rays(name, renderer_factory):
+    """Zero direction components (1/d = inf) and origins on box planes (0 * inf = NaN in the slab test):
+    the 4-wide nodes (trt_wide.h), their packed-fp32 box tests and the tiny-tree walk must all agree
+    with the oracle's binary recursion."""
+    s = get_scene(name, 64, 36)
+    org, dirs = raygen.adversarial_rays(s, 100000)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    t1, tri1, uv1 = renderer_factory(s).trace_closest(org, dirs)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+
+
 def test_trace_soup_deep_bvh(renderer_factory):
     s = get_scene("soup", 64, 36, n=200000)
     assert s.arrays()["bvh_depth"] > 12

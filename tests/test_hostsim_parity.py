@@ -50,6 +50,18 @@ def test_ordered_culled_traversal_visits_less_but_finds_the_same():
     assert cnt[0] < st.inner_visits[0] and cnt[1] < st.tri_tests[0]
 
 
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_wide_tree_on_degenerate_rays(name):
+    """The 4-wide collapse (trt_wide.h) drops intermediate boxes; the closest hit must not depend on that
+    even where the slab test meets 0 * inf (zero direction components, origins on box planes)."""
+    s = get_scene(name, 64, 36)
+    org, dirs = raygen.adversarial_rays(s, 30000)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    t1, tri1, uv1, _ = H.trace(s.flat, org, dirs)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+    assert (tri0 >= 0).sum() > 1000
+
+
 def test_device_code_on_synthetic_soup_and_tiles():
     s = T.Scene.named("soup", 48, 27, n=20000)
     p = T.make_params(48, 27, 4, T.SEED_SOUP)

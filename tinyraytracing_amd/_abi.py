@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-TRT_ABI_VERSION = 1
+TRT_ABI_VERSION = 2
 TRT_INF = 114514.0
 TRT_FLAG_TIMING = 1
 TRT_FLAG_COUNT = 2
@@ -71,7 +71,7 @@ class Stats(C.Structure):
                 ("shaded_hits", C.c_uint64), ("inner_visits", C.c_uint64 * 2), ("tri_tests", C.c_uint64 * 2), ("wave_steps", C.c_uint64 * 2),
                 ("launches", C.c_uint64 * TRT_MAX_KERNELS), ("kernel_ms", C.c_double * TRT_MAX_KERNELS),
                 ("render_ms", C.c_double), ("passes", C.c_uint32), ("max_bounces", C.c_uint32),
-                ("rows_rendered", C.c_uint64)]
+                ("rows_rendered", C.c_uint64), ("inner_node_bytes", C.c_uint32), ("reserved", C.c_uint32)]
 
     @property
     def rays(self):

@@ -13,6 +13,7 @@
 
 #include "trt.h"
 #include "trt_kernels.h"
+#include "trt_wide.h"
 
 using namespace trtd;
 
@@ -65,7 +66,8 @@ struct trt_handle {
     SceneDev sc{};
     std::vector<void*> scene_allocs;
     std::vector<uint32_t> light_mats;
-    uint32_t depth = 0;
+    uint32_t depth = 0;       // stack entries a traversal can need (wide tree), + 1
+    uint32_t bvh2_depth = 0;  // depth of the caller's BVH2
     uint32_t lds_tab[4] = {0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles that k_shade stages in LDS
     int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
     uint32_t tail_n = 32768;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
@@ -296,7 +298,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
 
     std::unique_ptr<trt_handle> h(new trt_handle);
     h->device = device;
-    h->depth = depth;
+    h->bvh2_depth = depth;
     if (const char* e = std::getenv("TRT_TAIL_N")) h->tail_n = (uint32_t)std::strtoul(e, nullptr, 10);
     // shallow trees (everything L1-resident, a dozen steps per ray): the static driver has the least overhead;
     // deeper ones gain more from lane refill and step scheduling (measured: DESIGN.md)
@@ -318,6 +320,12 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         if (int e = upload(h.get(), shade.data(), shade.size(), &h->sc.tri_shade)) return e;
     }
     if (int e = upload(h.get(), s->nodes, (size_t)s->n_nodes, &h->sc.nodes)) return e;
+    {   // the 4-wide collapse every per-lane traversal walks; its stack bound sizes the LDS stack / the spill area
+        const WideTree wide = collapseBvh(s->nodes, s->n_nodes);
+        if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
+        h->sc.n_wnodes = (uint32_t)wide.nodes.size();
+        h->depth = wide.stack_need + 1;
+    }
     {
         std::vector<MaterialDev> mats(s->n_materials);
         for (uint32_t i = 0; i < s->n_materials; ++i) mats[i] = makeMaterialDev(s->materials[i]);
@@ -375,7 +383,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     }
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
-    const uint32_t spill_levels = depth > (uint32_t)TRT_LDS_STACK_MAX ? depth - TRT_LDS_STACK_MAX + 1 : 1;
+    const uint32_t spill_levels = h->depth > (uint32_t)TRT_LDS_STACK_MAX ? h->depth - TRT_LDS_STACK_MAX + 1 : 1;
     h->spill_words_per_slot = (size_t)spill_levels * SPILL_STRIDE;
     if (int e = h->spill.ensure(h->spill_words_per_slot * 2 * sizeof(uint32_t))) return e;  // one area per concurrent pass
     for (hipStream_t& st : h->slot_streams) HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -660,6 +668,7 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     st.max_bounces = ds.max_depth_hit;
     st.passes = n_chunks;
     st.rows_rendered = rows.size();
+    st.inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (uint32_t)sizeof(WideNode);
     if (stats_out) *stats_out = st;
     return TRT_OK;
 }
@@ -732,6 +741,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
         stats_out->wave_steps[1] = ds.wave_leaf_steps;
         stats_out->kernel_ms[TRT_K_TRACE_CLOSEST] = ms;
         stats_out->launches[TRT_K_TRACE_CLOSEST] = 1;
+        stats_out->inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (uint32_t)sizeof(WideNode);
     }
     return TRT_OK;
 }

@@ -27,11 +27,6 @@ namespace trtd {
 // Build-time tuning knobs (A/B variants are built by `make variants` and picked with TRT_HIP_LIB):
 //   TRT_TRACE_MINWAVES  second __launch_bounds__ argument of the traversal kernels (0 = leave it to the compiler)
 //   TRT_PREFETCH        (trt_path.h) fetch the next triangle record of a leaf while the current one is tested
-// TRT_STACK_TENTRY: keep the box entry distance with every stack entry (bf16, +2 B per level and lane) and
-// cull at pop time (persistent drivers)
-#ifndef TRT_STACK_TENTRY
-#define TRT_STACK_TENTRY 0
-#endif
 #ifndef TRT_TRACE_MINWAVES
 #define TRT_TRACE_MINWAVES 0
 #endif
@@ -101,14 +96,6 @@ struct LdsStack {
         if (sp >= DEPTH) v = spill[(size_t)(sp - DEPTH) * spill_stride];
         return v;
     }
-#if TRT_STACK_TENTRY
-    // Box entry distance of every LDS-resident entry, as the upper 16 bits of the float (for t >= 0 that
-    // rounds DOWN, so "entry > best" on it can only under-cull, never drop a node that might still win).
-    // At pop time a subtree whose entry is strictly beyond the current best hit is skipped without fetching it.
-    uint16_t* lds_t;  // &smem_t[threadIdx.x]
-    __device__ void pushT(int sp, float t) { if (sp < DEPTH) lds_t[sp * TRT_TRACE_BLOCK] = (uint16_t)(f2u(t) >> 16); }
-    __device__ float popT(int sp) const { return sp < DEPTH ? u2f((uint32_t)lds_t[sp * TRT_TRACE_BLOCK] << 16) : 0.0f; }
-#endif
 };
 
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a
@@ -320,9 +307,6 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
     stk.lds = smem + threadIdx.x;
     stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
     stk.spill_stride = spill_stride;
-#if TRT_STACK_TENTRY
-    stk.lds_t = reinterpret_cast<uint16_t*>(smem + DEPTH * TRT_TRACE_BLOCK) + threadIdx.x;
-#endif
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lower = (1ull << lane) - 1ull;
     // contiguous queue slice of this wave (XCD-aware: neighbouring slices share an L2)
@@ -386,25 +370,10 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             const unsigned long long m = __ballot(is_inner);
             if (m == 0ull) break;
             if (is_inner) {
-                const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + cur);
-                const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
-                float e0, e1;
-                bool h0 = boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
-                bool h1 = boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
-                const uint32_t child0 = f2u(q3.x), child1 = f2u(q3.y);
-                h0 = h0 && !(e0 > best_t);  // skipped only when STRICTLY beyond the best hit: ties are still visited
-                h1 = h1 && !(e1 > best_t);
-                if (h0 && h1) {
-                    const bool swap = e1 < e0;
-                    stk.push(sp++, swap ? child0 : child1);
-                    cur = swap ? child1 : child0;
-                } else if (h0 || h1) {
-                    cur = h0 ? child0 : child1;
-                } else if (sp == 0) {
-                    cur = TRT_REF_DONE;
-                } else {
-                    cur = stk.pop(--sp);
+                if (!innerStep(sc, cur, sp, stk, o, inv, best_t)) {
+                    if (sp == 0) cur = TRT_REF_DONE;
+                    else cur = stk.pop(--sp);
                 }
             }
         }
@@ -449,29 +418,9 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         if (__popcll(m_in) >= __popcll(m_lf)) {
             // ---- inner-node step
             if (is_inner) {
-                const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + cur);
-                const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
-                float e0, e1;
-                bool h0 = boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
-                bool h1 = boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
-                const uint32_t child0 = f2u(q3.x), child1 = f2u(q3.y);
-                h0 = h0 && !(e0 > best_t);  // skipped only when STRICTLY beyond the best hit: ties are still visited
-                h1 = h1 && !(e1 > best_t);
-                if (h0 && h1) {
-                    const bool swap = e1 < e0;
-#if TRT_STACK_TENTRY
-                    stk.pushT(sp, swap ? e0 : e1);
-#endif
-                    stk.push(sp++, swap ? child0 : child1);
-                    cur = swap ? child1 : child0;
-                    lk = 0; lt = TRT_INF; li = -1;
-                } else if (h0 || h1) {
-                    cur = h0 ? child0 : child1;
-                    lk = 0; lt = TRT_INF; li = -1;
-                } else {
-                    adv = true;
-                }
+                if (innerStep(sc, cur, sp, stk, o, inv, best_t)) { lk = 0; lt = TRT_INF; li = -1; }
+                else adv = true;
             }
         } else {
             // ---- leaf step: one triangle of interactBVHNode's loop (bvh.cpp:211-229), index order
@@ -502,16 +451,8 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             }
         }
         if (adv) {
-#if TRT_STACK_TENTRY
-            cur = TRT_REF_DONE;
-            while (sp != 0) {
-                --sp;
-                if (!(stk.popT(sp) > best_t)) { cur = stk.pop(sp); break; }  // else: strictly beyond the best hit, drop it unfetched
-            }
-#else
             if (sp == 0) cur = TRT_REF_DONE;
             else cur = stk.pop(--sp);
-#endif
             lk = 0; lt = TRT_INF; li = -1;
         }
         }
@@ -543,7 +484,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
-    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK + (TRT_STACK_TENTRY ? DEPTH * TRT_TRACE_BLOCK / 2 : 0)];
+    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
     traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem);
 }
 
@@ -555,7 +496,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
-    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK + (TRT_STACK_TENTRY ? DEPTH * TRT_TRACE_BLOCK / 2 : 0)];
+    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;

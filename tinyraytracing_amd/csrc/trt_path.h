@@ -105,8 +105,20 @@ struct TextureDev {
     uint64_t offset;  // into tex_bytes
 };
 
+// 4-wide inner node, 128 B = eight 16-B loads, children side by side (one float4 per box plane):
+//   q[0..2] = lo.x, lo.y, lo.z of children 0..3    q[3..5] = hi.x, hi.y, hi.z
+//   q[6]    = child references (trt.h encoding; an inner reference indexes wnodes)    q[7] unused
+// An unused slot holds an all-NaN box (fails every slab test) and TRT_WIDE_EMPTY.  Built from the
+// caller's BVH2 by collapseBvh (trt_wide.h), which also says why the closest hit cannot change.
+#define TRT_WIDE 4
+#define TRT_WIDE_EMPTY 0xFFFFFFFFu
+struct WideNode {
+    f4 q[8];
+};
+
 struct SceneDev {
-    const trt_bvh_node* nodes;
+    const trt_bvh_node* nodes;   // the caller's BVH2: the wave-uniform walk of tiny trees (trt_kernels.h, IMPL 0)
+    const WideNode* wnodes;      // its 4-wide collapse: every per-lane traversal
     const TriIsect* tri_isect;
     const TriShade* tri_shade;
     const MaterialDev* materials;
@@ -115,7 +127,7 @@ struct SceneDev {
     const float* light_cum;  // light_tris[k].cum_area packed (the CDF of pathTracing.cpp:40); null = scan the structs
     const TextureDev* textures;
     const uint8_t* tex_bytes;
-    uint32_t n_tris, n_nodes, n_lights;
+    uint32_t n_tris, n_nodes, n_wnodes, n_lights;
     float light0_area;  // Q3: every light's CDF draw spans lights[0].area (pathTracing.cpp:38)
     trt_camera cam;
 };
@@ -193,7 +205,13 @@ TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& u
     const float tn_s = fmaf(e2z, qz, fmaf(e2y, qy, e2x * qx));
     const uint32_t sgn = f2u(det_s) & 0x80000000u;  // exact negation of all four when det < 0
     const float det = u2f(f2u(det_s) ^ sgn), un = u2f(f2u(un_s) ^ sgn), vn = u2f(f2u(vn_s) ^ sgn), tn = u2f(f2u(tn_s) ^ sgn);
-    const bool cand = !(det < T.c.y) && un > 0.0f && vn > 0.0f && (un + vn) < det;  // bvh.cpp:185,196-198
+    // bvh.cpp:185,196-198: !(det < tol) && un > 0 && vn > 0 && un + vn < det.  The three "> 0" tests as one
+    // integer comparison: x > 0 (NaN: false, +inf: true) <=> bits(x) - 1 < 0x7F800000 unsigned, and
+    // un + vn < det <=> det - (un + vn) > 0 (exact with gradual underflow; inf - inf = NaN is false on both sides).
+    const float rest = det - (un + vn);
+    const uint32_t bu = f2u(un) - 1u, bv = f2u(vn) - 1u, br = f2u(rest) - 1u;
+    const uint32_t bmax = bu > bv ? (bu > br ? bu : br) : (bv > br ? bv : br);
+    const bool cand = !(det < T.c.y) && bmax < 0x7F800000u;
     if (!cand) return false;
     const float t = tn / det;
     if (t < TRT_T_MIN) return false;  // bvh.cpp:189
@@ -208,15 +226,80 @@ TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& u
 // bvh.cpp:231-245: slab test; `entry` receives t0 (used for ordering/culling).
 // fminf/fmaxf differ from glm's ternaries only for NaN operands (an axis with
 // d == 0 and the origin exactly on the padded plane).
-TRT_HD inline bool boxTest(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float& entry)
+TRT_HD inline bool slabResult(float inx, float iny, float inz, float outx, float outy, float outz, float& entry)
 {
-    const float inx = (hix - o.x) * inv.x, iny = (hiy - o.y) * inv.y, inz = (hiz - o.z) * inv.z;
-    const float outx = (lox - o.x) * inv.x, outy = (loy - o.y) * inv.y, outz = (loz - o.z) * inv.z;
     const float t1 = fminf(fmaxf(inx, outx), fminf(fmaxf(iny, outy), fmaxf(inz, outz)));
     const float t0 = fmaxf(fminf(inx, outx), fmaxf(fminf(iny, outy), fminf(inz, outz)));
     entry = t0;
     const float r = (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
     return r > 0.0f;  // the caller descends iff the result is > 0 (bvh.cpp:162-166)
+}
+TRT_HD inline bool boxTest(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float& entry)
+{
+    const float inx = (hix - o.x) * inv.x, iny = (hiy - o.y) * inv.y, inz = (hiz - o.z) * inv.z;
+    const float outx = (lox - o.x) * inv.x, outy = (loy - o.y) * inv.y, outz = (loz - o.z) * inv.z;
+    return slabResult(inx, iny, inz, outx, outy, outz, entry);
+}
+
+// ------------------------------------------------------ one inner-node step ----
+// Children of wide node `cur` that the ray can still improve on: box passed (bvh.cpp:162-166) and entry
+// not STRICTLY beyond the best hit.  Continues with the nearest (returns true, `cur` updated), the others
+// go on the stack, nearest on top.  The visiting order is free (see traceClosest); only the set matters.
+#define TRT_CSWAP(ka, ra, kb, rb)                                   \
+    {                                                               \
+        const bool sw_ = kb < ka;                                   \
+        const float tk_ = sw_ ? kb : ka;                            \
+        const uint32_t tr_ = sw_ ? rb : ra;                         \
+        kb = sw_ ? ka : kb;                                         \
+        rb = sw_ ? ra : rb;                                         \
+        ka = tk_;                                                   \
+        ra = tr_;                                                   \
+    }
+template <class Stack>
+TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& stk, f3 o, f3 inv, float best_t)
+{
+    const f4* np4 = sc.wnodes[cur].q;
+    const f4 lx = np4[0], ly = np4[1], lz = np4[2], hx = np4[3], hy = np4[4], hz = np4[5], rf = np4[6];
+    float e0, e1, e2, e3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The 24 subtractions and 24 multiplications of four slab tests as packed-fp32 pairs (v_pk_add_f32 /
+    // v_pk_mul_f32: two IEEE operations per lane and instruction, children (0,1) and (2,3) side by side);
+    // every element is computed by the same operation as in boxTest().
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const v2f inx_a = (v2f{hx.x, hx.y} - ox) * ix, inx_b = (v2f{hx.z, hx.w} - ox) * ix;
+    const v2f iny_a = (v2f{hy.x, hy.y} - oy) * iy, iny_b = (v2f{hy.z, hy.w} - oy) * iy;
+    const v2f inz_a = (v2f{hz.x, hz.y} - oz) * iz, inz_b = (v2f{hz.z, hz.w} - oz) * iz;
+    const v2f outx_a = (v2f{lx.x, lx.y} - ox) * ix, outx_b = (v2f{lx.z, lx.w} - ox) * ix;
+    const v2f outy_a = (v2f{ly.x, ly.y} - oy) * iy, outy_b = (v2f{ly.z, ly.w} - oy) * iy;
+    const v2f outz_a = (v2f{lz.x, lz.y} - oz) * iz, outz_b = (v2f{lz.z, lz.w} - oz) * iz;
+    const bool h0 = slabResult(inx_a.x, iny_a.x, inz_a.x, outx_a.x, outy_a.x, outz_a.x, e0) && !(e0 > best_t);
+    const bool h1 = slabResult(inx_a.y, iny_a.y, inz_a.y, outx_a.y, outy_a.y, outz_a.y, e1) && !(e1 > best_t);
+    const bool h2 = slabResult(inx_b.x, iny_b.x, inz_b.x, outx_b.x, outy_b.x, outz_b.x, e2) && !(e2 > best_t);
+    const bool h3 = slabResult(inx_b.y, iny_b.y, inz_b.y, outx_b.y, outy_b.y, outz_b.y, e3) && !(e3 > best_t);
+#else
+    const bool h0 = boxTest(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, o, inv, e0) && !(e0 > best_t);
+    const bool h1 = boxTest(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, o, inv, e1) && !(e1 > best_t);
+    const bool h2 = boxTest(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, o, inv, e2) && !(e2 > best_t);
+    const bool h3 = boxTest(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, o, inv, e3) && !(e3 > best_t);
+#endif
+    const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    if (n == 0) return false;
+    // sort by entry distance; children that are not visited get a key no visited one can reach (a visited
+    // entry is <= best_t <= TRT_INF) and so end up last
+    const float skip = 3.0e38f;
+    float k0 = h0 ? e0 : skip, k1 = h1 ? e1 : skip, k2 = h2 ? e2 : skip, k3 = h3 ? e3 : skip;
+    uint32_t r0 = f2u(rf.x), r1 = f2u(rf.y), r2 = f2u(rf.z), r3 = f2u(rf.w);
+    TRT_CSWAP(k0, r0, k1, r1)
+    TRT_CSWAP(k2, r2, k3, r3)
+    TRT_CSWAP(k0, r0, k2, r2)
+    TRT_CSWAP(k1, r1, k3, r3)
+    TRT_CSWAP(k1, r1, k2, r2)
+    if (n > 3) stk.push(sp++, r3);
+    if (n > 2) stk.push(sp++, r2);
+    if (n > 1) stk.push(sp++, r1);
+    cur = r0;
+    return true;
 }
 
 // ------------------------------------------------------ traverseBVH (a3) ----
@@ -281,25 +364,8 @@ TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
             cur = stk.pop(--sp);
             continue;
         }
-        // one 64-B node = four 16-B loads: (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (child0, child1, -, -)
-        const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + cur);
-        const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
         if (COUNT) n_inner++;
-        float e0, e1;
-        bool h0 = boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
-        bool h1 = boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
-        const uint32_t child0 = f2u(q3.x), child1 = f2u(q3.y);
-        h0 = h0 && !(e0 > best.t);
-        h1 = h1 && !(e1 > best.t);
-        if (h0 && h1) {
-            const bool swap = e1 < e0;
-            stk.push(sp++, swap ? child0 : child1);
-            cur = swap ? child1 : child0;
-        } else if (h0) {
-            cur = child0;
-        } else if (h1) {
-            cur = child1;
-        } else {
+        if (!innerStep(sc, cur, sp, stk, o, inv, best.t)) {
             if (sp == 0) break;
             cur = stk.pop(--sp);
         }

@@ -1,0 +1,126 @@
+// trt_wide.h — host side: collapses the caller's BVH2 (include/trt.h, trt_bvh_node) into the 4-wide
+// nodes the per-lane traversal walks (WideNode, trt_path.h).  Used by trt_create (trt_api.hip) and by
+// tests/hostsim, so both sides walk the very same tree.
+//
+// Why the result of a ray cannot change: a wide node keeps the leaves and the leaf order of the binary
+// tree and only drops some intermediate boxes.  The reference descends into a child iff the ray passes
+// the child's box test (bvh.cpp:156-166), so a leaf is reached iff the ray passes every box on its
+// root path.  The slab test (boxTest, trt_path.h) is monotone in the box: when box P contains box C,
+// every per-axis bound of C lies inside P's ((x - o) * inv is monotone in x under rounding, fminf/fmaxf
+// drop NaNs the same way for both), so "passes C" implies "passes P" and entry(P) <= entry(C).  Dropping
+// P's test therefore never changes which leaves are reached, nor what is culled by the best hit.  An
+// intermediate node whose box does NOT contain both of its children's boxes (possible only in a tree
+// handed over by a foreign builder) is kept as a node of its own and never dropped.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+#include "trt_path.h"
+
+namespace trtd {
+
+struct WideTree {
+    std::vector<WideNode> nodes;  // nodes[0] is the root
+    uint32_t stack_need = 0;      // upper bound of the traversal stack: max over root paths of sum(children - 1)
+    uint64_t dropped = 0;         // intermediate boxes dropped
+};
+
+namespace wide_detail {
+struct Box { float lo[3], hi[3]; };
+struct Entry { Box b; uint32_t ref; };  // ref: BVH2 child reference (leaf bit or BVH2 node index)
+
+inline float halfArea(const Box& b)
+{
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+inline bool contains(const Box& p, const Box& c)
+{
+    for (int a = 0; a < 3; ++a)
+        if (!(p.lo[a] <= c.lo[a] && p.hi[a] >= c.hi[a])) return false;
+    return true;
+}
+inline void children(const trt_bvh_node& n, Entry out[2])
+{
+    for (int a = 0; a < 3; ++a) {
+        out[0].b.lo[a] = n.lo0[a]; out[0].b.hi[a] = n.hi0[a];
+        out[1].b.lo[a] = n.lo1[a]; out[1].b.hi[a] = n.hi1[a];
+    }
+    out[0].ref = n.child0;
+    out[1].ref = n.child1;
+}
+}  // namespace wide_detail
+
+// `nodes` must have passed validateBvh (every inner node reachable exactly once, indices in range).
+inline WideTree collapseBvh(const trt_bvh_node* nodes, uint32_t n_nodes)
+{
+    using namespace wide_detail;
+    WideTree w;
+    if (n_nodes == 0) return w;
+    w.nodes.reserve(n_nodes / 2 + 1);
+    struct Job { uint32_t bvh2, wide; };
+    std::vector<Job> jobs;
+    std::vector<uint32_t> parent_need;  // per wide node: sum(children-1) over the path from the root to it, inclusive
+    w.nodes.emplace_back();
+    parent_need.push_back(0);
+    jobs.push_back({0u, 0u});
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    while (!jobs.empty()) {
+        const Job j = jobs.back();
+        jobs.pop_back();
+        Entry e[TRT_WIDE];
+        int n = 2;
+        children(nodes[j.bvh2], e);
+        while (n < TRT_WIDE) {
+            // open the inner child with the largest box whose own box contains both of its children's
+            int pick = -1;
+            float best = -1.0f;
+            for (int k = 0; k < n; ++k) {
+                if (e[k].ref & TRT_LEAF_BIT) continue;
+                Entry c[2];
+                children(nodes[e[k].ref], c);
+                if (!contains(e[k].b, c[0].b) || !contains(e[k].b, c[1].b)) continue;
+                const float a = halfArea(e[k].b);
+                if (a > best || pick < 0) { best = a; pick = k; }
+            }
+            if (pick < 0) break;
+            Entry c[2];
+            children(nodes[e[pick].ref], c);
+            for (int k = n; k > pick + 1; --k) e[k] = e[k - 1];  // keep the left-to-right (leaf index) order
+            e[pick] = c[0];
+            e[pick + 1] = c[1];
+            ++n;
+            ++w.dropped;
+        }
+        const uint32_t need = parent_need[j.wide] + (uint32_t)(n - 1);
+        if (need > w.stack_need) w.stack_need = need;
+        WideNode wn;
+        for (int k = 0; k < TRT_WIDE; ++k) {
+            float* q = reinterpret_cast<float*>(wn.q);
+            uint32_t ref = TRT_WIDE_EMPTY;
+            if (k < n) {
+                for (int a = 0; a < 3; ++a) { q[a * 4 + k] = e[k].b.lo[a]; q[(3 + a) * 4 + k] = e[k].b.hi[a]; }
+                if (e[k].ref & TRT_LEAF_BIT) {
+                    ref = e[k].ref;
+                } else {
+                    ref = (uint32_t)w.nodes.size();
+                    w.nodes.emplace_back();
+                    parent_need.push_back(need);
+                    jobs.push_back({e[k].ref, ref});
+                }
+            } else {
+                for (int a = 0; a < 6; ++a) q[a * 4 + k] = qnan;  // an all-NaN box fails every slab test
+            }
+            uint32_t* qu = reinterpret_cast<uint32_t*>(wn.q);  // integer view: child references are not floats
+            qu[6 * 4 + k] = ref;
+            qu[7 * 4 + k] = 0u;
+        }
+        w.nodes[j.wide] = wn;
+    }
+    return w;
+}
+
+}  // namespace trtd
