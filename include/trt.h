@@ -207,6 +207,16 @@ int trt_render(trt_handle* h, const trt_params* p, float* out_rgb_host, trt_stat
 int trt_render_device(trt_handle* h, const trt_params* p, float* out_rgb_dev,
                       void* hip_stream, trt_stats* stats);
 
+/* Progressive / resumable render.  The reference keeps one `double* image` for the whole run and adds
+ * color/SAMPLE of every sample to it (main.cpp:74-75,101), then shows it once at the end (main.cpp:114).
+ * This entry renders samples [sample_begin, sample_end) of the p->spp samples and adds them, in sample
+ * order, onto `accum` — HOST, rows_selected * (x1-x0) * 3 doubles, in/out: the running sums of
+ * (double)(L_s / spp).  Calls that cover [0, spp) in increasing order, starting from zeros, leave exactly
+ * the sums of one trt_render call (and in out_rgb_host — optional, may be NULL — exactly its image), so
+ * a long render can be shown while it converges, check-pointed (save accum + sample_end) and resumed. */
+int trt_render_samples(trt_handle* h, const trt_params* p, int32_t sample_begin, int32_t sample_end,
+                       double* accum_host, float* out_rgb_host, trt_stats* stats);
+
 /* traverseBVH (bvh.cpp:146-175) on a batch of n rays given as HOST arrays
  * org[n][3], dir[n][3].  Outputs (host): t[n] (TRT_INF on miss), tri[n]
  * (post-BVH triangle index, -1 on miss), uv[n][2] (barycentrics of v1,v2).

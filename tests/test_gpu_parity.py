@@ -327,3 +327,55 @@ def test_error_codes(renderer_factory):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+# ------------------------------------------------------------------ progressive / resumable render
+def test_render_samples_resumes_bit_exactly(renderer_factory):
+    """trt_render_samples over [0,5), [5,6), [6,16) from zeros == one trt_render of 16 spp == the oracle; the
+    accumulator may take a round trip through a file in between (checkpoint)."""
+    s = get_scene("veach-mis", 80, 45)
+    r = renderer_factory(s)
+    p = T.make_params(80, 45, 16, 0xC0FFEE)
+    full, st_full = r.render(p)
+    ref, ost = O.render(s.flat, p)
+    assert np.array_equal(full, ref)
+    acc, rays = None, 0
+    for a, b in ((0, 5), (5, 6), (6, 16)):
+        img, acc, st = r.render_samples(p, a, b, acc)
+        acc = np.frombuffer(acc.tobytes(), dtype=np.float64).reshape(acc.shape).copy()  # what a checkpoint file holds
+        rays += st.rays
+        if b < 16:
+            assert not np.array_equal(img, full)
+    assert np.array_equal(img, full)
+    assert rays == st_full.rays == ost.rays
+    # overlapping passes (two slots) leave the same sums
+    img2, acc2, _ = r.render_samples(T.make_params(80, 45, 16, 0xC0FFEE, flags=T.TRT_FLAG_OVERLAP), 0, 16, None)
+    assert np.array_equal(img2, full) and np.array_equal(acc2, acc)
+    for bad in ((-1, 4), (4, 4), (3, 17)):
+        with pytest.raises(T.TrtError):
+            r.render_samples(p, bad[0], bad[1], None)
+
+
+def test_cli_progressive_render_resumes_from_its_checkpoint(tmp_path):
+    """tinyrt (host/main.cpp = the reference's main()): one-shot PNG == PNG of a run that was stopped after 6 of
+    16 samples and resumed from its accumulator file == the library's image through tonemap (main.cpp:34)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(T.__file__), "lib", "tinyrt")
+    d = os.path.join(os.path.dirname(T.__file__), "..", "scenes", "back")
+    base = [exe, d, os.path.join(d, "back.mtl"), os.path.join(d, "back.xml"), os.path.join(d, "back.obj"), "16", "--width", "96", "--height", "54", "--seed", "77"]
+    a, b, ck = str(tmp_path / "a.png"), str(tmp_path / "b.png"), str(tmp_path / "b.acc")
+    subprocess.run(base + ["--out", a], check=True, capture_output=True, timeout=300)
+    subprocess.run(base + ["--out", b, "--every", "3", "--checkpoint", ck, "--stop-after", "6"], check=True, capture_output=True, timeout=300)
+    partial = open(b, "rb").read()
+    assert partial != open(a, "rb").read()
+    subprocess.run(base + ["--out", b, "--every", "5", "--checkpoint", ck], check=True, capture_output=True, timeout=300)
+    assert open(b, "rb").read() == open(a, "rb").read()
+    # a finished checkpoint reproduces the picture without rendering; one of another render is refused
+    subprocess.run(base + ["--out", b, "--checkpoint", ck], check=True, capture_output=True, timeout=300)
+    assert open(b, "rb").read() == open(a, "rb").read()
+    bad = subprocess.run(base[:-1] + ["78", "--out", b, "--checkpoint", ck], capture_output=True, timeout=300)
+    assert bad.returncode != 0 and b"another render" in bad.stderr
+    s = get_scene("back", 96, 54)
+    img, _ = T.Renderer(s, 0).render(T.make_params(96, 54, 16, 77))
+    T.imshow(img, str(tmp_path / "c.png"))
+    assert open(str(tmp_path / "c.png"), "rb").read() == open(a, "rb").read()

@@ -181,6 +181,26 @@ class Renderer:
             raise TrtError(f"trt_render failed ({rc}): {self._lib.trt_last_error().decode()}")
         return out, st
 
+    def render_samples(self, params, sample_begin, sample_end, accum=None):
+        """Progressive render (trt_render_samples): adds samples [sample_begin, sample_end) of params.spp onto
+        `accum` (float64 [rows, tile_w, 3], the running per-pixel sums; None = start from zeros).
+        Returns (image so far, accum, Stats); save accum + sample_end to checkpoint, pass them back to resume."""
+        nrows = self._lib.trt_rows_selected(C.byref(params))
+        tw = params.x1 - params.x0
+        if nrows <= 0 or tw <= 0:
+            raise TrtError("render_samples: empty tile")
+        if accum is None:
+            accum = np.zeros((nrows, tw, 3), dtype=np.float64)
+        if accum.dtype != np.float64 or accum.shape != (nrows, tw, 3) or not accum.flags["C_CONTIGUOUS"]:
+            raise TrtError("render_samples: accum must be a contiguous float64 array of shape (rows, tile_w, 3)")
+        out = np.empty((nrows, tw, 3), dtype=np.float32)
+        st = Stats()
+        rc = self._lib.trt_render_samples(self._h, C.byref(params), int(sample_begin), int(sample_end), accum.ctypes.data_as(C.POINTER(C.c_double)),
+                                          out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
+        if rc != 0:
+            raise TrtError(f"trt_render_samples failed ({rc}): {self._lib.trt_last_error().decode()}")
+        return out, accum, st
+
     def render_into(self, params, out_tensor, stream_ptr=0):
         """Renders into a CUDA/HIP torch tensor (float32, >= rows*tile_w*3 elements) on this device."""
         nrows = self._lib.trt_rows_selected(C.byref(params))

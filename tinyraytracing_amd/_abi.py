@@ -79,7 +79,7 @@ class Stats(C.Structure):
 
 
 # the symbols include/trt.h declares (checked by tests/test_abi.py)
-HIP_SYMBOLS = ["trt_rows_selected", "trt_create", "trt_render", "trt_render_device", "trt_trace_closest",
+HIP_SYMBOLS = ["trt_rows_selected", "trt_create", "trt_render", "trt_render_device", "trt_render_samples", "trt_trace_closest",
                "trt_destroy", "trt_last_error", "trt_abi_version"]
 HOST_SYMBOLS = ["trth_scene_load", "trth_scene_drop_tris", "trth_scene_add_soup", "trth_scene_add_blob",
                 "trth_scene_build", "trth_scene_flat", "trth_scene_info", "trth_scene_light_area",
@@ -161,6 +161,7 @@ def load_hip():
     lib.trt_create.argtypes = [C.POINTER(SceneFlat), C.c_int, C.POINTER(C.c_void_p)]
     lib.trt_render.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(Stats)]
     lib.trt_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    lib.trt_render_samples.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(Stats)]
     lib.trt_trace_closest.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(Stats)]
     lib.trt_destroy.argtypes = [C.c_void_p]

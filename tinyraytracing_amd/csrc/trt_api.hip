@@ -37,7 +37,11 @@ int fail(int code, const std::string& msg)
 constexpr uint32_t MAX_TRACE_BLOCKS = 8192;                       // persistent grid cap of the traversal kernels
 constexpr uint32_t SPILL_STRIDE = MAX_TRACE_BLOCKS * TRT_TRACE_BLOCK;
 constexpr uint32_t MAX_BOUNCES = TRT_MAX_PATH_DEPTH + 2;
-constexpr uint32_t COUNT_ROW = 16;                                // u32 per bounce: [0] = queue length, [1+l] = shadow rays of light l
+constexpr uint32_t COUNT_ROW = 16;                                // counters per bounce: [0] = queue length, [1+l] = shadow rays of light l
+// Device layout of the counters: counter c of bounce b lives at d_counts[c * COUNT_STRIDE + b], so the
+// counters k_shade bumps in one launch lie 16 KiB apart (different L2 channels: the atomic units work in
+// parallel) instead of in one cache line.
+constexpr uint32_t COUNT_STRIDE = (MAX_BOUNCES + 2 + 1023u) & ~1023u;
 constexpr uint32_t MAX_BVH_DEPTH = 256;
 
 struct DevBuf {
@@ -422,10 +426,16 @@ struct PassSlot {
 };
 }  // namespace
 
-int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* hip_stream, trt_stats* stats_out)
+namespace {
+// The render loop behind trt_render_device / trt_render / trt_render_samples: samples [s_begin, s_end) of
+// p->spp, added in sample order onto the per-pixel double sums (`accum_host`: in/out when given, else the
+// sums start at zero and are dropped), then rounded to float into out_dev.
+int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_end, float* out_dev, void* hip_stream, trt_stats* stats_out, double* accum_host)
 {
     if (int e = checkParams(h, p)) return e;
     if (!out_dev) return fail(TRT_EINVAL, "null output buffer");
+    if (s_begin >= s_end || s_end > (uint32_t)p->spp) return fail(TRT_EINVAL, "sample range must satisfy 0 <= begin < end <= spp");
+    const uint32_t n_samples = s_end - s_begin;
     HIPC(hipSetDevice(h->device));
     hipStream_t stream = (hipStream_t)hip_stream;
     const bool count = (p->flags & TRT_FLAG_COUNT) != 0;
@@ -448,16 +458,16 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         HIPC(hipMemGetInfo(&free_b, &total_b));
         budget = std::min<uint64_t>((uint64_t)(free_b + h->arena.bytes) / 2, 32ull << 30);
     }
-    const int n_slots = (p->spp >= 2 && (p->flags & TRT_FLAG_OVERLAP) && h->n_slots > 1) ? N_SLOTS : 1;
+    const int n_slots = (n_samples >= 2 && (p->flags & TRT_FLAG_OVERLAP) && h->n_slots > 1) ? N_SLOTS : 1;
     uint64_t max_paths = std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull);
     if (max_paths < npix) return fail(TRT_ENOMEM, "mem_budget too small for one sample of every pixel of the tile; render smaller tiles");
     if (n_slots > 1 && max_paths / n_slots >= npix) max_paths /= n_slots;  // each slot gets its share of the budget
     const int slots_used = (max_paths * n_slots <= std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull)) ? n_slots : 1;
-    uint32_t s_chunk = (uint32_t)std::min<uint64_t>((uint64_t)p->spp, max_paths / npix);
-    uint32_t n_chunks = ((uint32_t)p->spp + s_chunk - 1) / s_chunk;
-    if (slots_used > 1 && n_chunks < (uint32_t)slots_used) n_chunks = (uint32_t)std::min<uint32_t>((uint32_t)slots_used, (uint32_t)p->spp);
-    s_chunk = ((uint32_t)p->spp + n_chunks - 1) / n_chunks;
-    n_chunks = ((uint32_t)p->spp + s_chunk - 1) / s_chunk;
+    uint32_t s_chunk = (uint32_t)std::min<uint64_t>((uint64_t)n_samples, max_paths / npix);
+    uint32_t n_chunks = (n_samples + s_chunk - 1) / s_chunk;
+    if (slots_used > 1 && n_chunks < (uint32_t)slots_used) n_chunks = (uint32_t)std::min<uint32_t>((uint32_t)slots_used, n_samples);
+    s_chunk = (n_samples + n_chunks - 1) / n_chunks;
+    n_chunks = (n_samples + s_chunk - 1) / s_chunk;
     const uint64_t N = (uint64_t)npix * s_chunk;
 
     // ---- carve the arena: one set of queues per slot -------------------------------
@@ -465,7 +475,7 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     const size_t per_slot = q16 * (3 * 2 + 1 + 1 + 3 * (size_t)nl);
     if (int e = h->arena.ensure(per_slot * (size_t)slots_used)) return e;
     const size_t rows_bytes = (rows.size() * sizeof(int32_t) + 255) & ~(size_t)255;
-    const size_t counts_bytes = (size_t)(MAX_BOUNCES + 2) * COUNT_ROW * sizeof(uint32_t);
+    const size_t counts_bytes = (size_t)COUNT_STRIDE * COUNT_ROW * sizeof(uint32_t);
     const size_t stats_bytes = 256;
     const size_t acc_bytes = (size_t)npix * 3 * sizeof(double);
     if (int e = h->small_buf.ensure(rows_bytes + counts_bytes * N_SLOTS + stats_bytes + acc_bytes)) return e;
@@ -492,7 +502,8 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
 
     HIPC(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIPC(hipMemsetAsync(d_stats, 0, sizeof(DeviceStats), stream));
-    HIPC(hipMemsetAsync(d_acc, 0, acc_bytes, stream));
+    if (accum_host) HIPC(hipMemcpyAsync(d_acc, accum_host, acc_bytes, hipMemcpyHostToDevice, stream));
+    else HIPC(hipMemsetAsync(d_acc, 0, acc_bytes, stream));
 
     TileDesc td;
     td.rows = d_rows;
@@ -517,8 +528,8 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     auto startPass = [&](PassSlot& S) -> int {
         if (next_chunk >= n_chunks) { S.state = PassSlot::IDLE; return TRT_OK; }
         S.chunk = next_chunk++;
-        S.s0 = S.chunk * s_chunk;
-        S.sc_count = std::min(s_chunk, (uint32_t)p->spp - S.s0);
+        S.s0 = s_begin + S.chunk * s_chunk;
+        S.sc_count = std::min(s_chunk, s_end - S.s0);
         S.n_active = npix * S.sc_count;
         S.b = 0;
         S.cur = 0;
@@ -551,8 +562,9 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         A.n = S.n_active;
         A.qout = S.Q[S.cur ^ 1];
         for (int l = 0; l < TRT_MAX_LIGHTS; ++l) A.sq[l] = S.SQ[l];
-        A.next_count = S.d_counts + (size_t)(S.b + 1) * COUNT_ROW;
-        A.shadow_counts = S.d_counts + (size_t)S.b * COUNT_ROW + 1;
+        A.next_count = S.d_counts + (size_t)(S.b + 1);
+        A.shadow_counts = S.d_counts + (size_t)COUNT_STRIDE + S.b;  // light l: + l * COUNT_STRIDE
+        A.shadow_count_stride = COUNT_STRIDE;
         A.Lacc = S.Lacc;
         A.td = td;
         A.s0 = S.s0;
@@ -567,7 +579,9 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
         hipLaunchKernelGGL(k_shade, dim3(std::min<uint32_t>((S.n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u)), dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A);
         tm.end(S.stream);
         st.launches[TRT_K_SHADE]++;
-        HIPC(hipMemcpyAsync(S.host_counts, S.d_counts + (size_t)S.b * COUNT_ROW, 2 * COUNT_ROW * sizeof(uint32_t), hipMemcpyDeviceToHost, S.stream));
+        // (b, c) and (b + 1, c) of the counters in use -> host_counts[2 * c], [2 * c + 1]
+        HIPC(hipMemcpy2DAsync(S.host_counts, 2 * sizeof(uint32_t), S.d_counts + S.b, (size_t)COUNT_STRIDE * sizeof(uint32_t), 2 * sizeof(uint32_t), 1 + nl,
+                              hipMemcpyDeviceToHost, S.stream));
         S.state = PassSlot::WAIT;
         return TRT_OK;
     };
@@ -575,7 +589,7 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     auto completeBounce = [&](PassSlot& S) -> int {
         HIPC(hipStreamSynchronize(S.stream));
         for (uint32_t l = 0; l < nl; ++l) {
-            const uint32_t ns = S.host_counts[1 + l];
+            const uint32_t ns = S.host_counts[2 * (1 + l)];
             if (ns > S.n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");
             if (!ns) continue;
             tm.begin(TRT_K_TRACE_SHADOW, S.stream);
@@ -585,7 +599,7 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
             st.launches[TRT_K_TRACE_SHADOW]++;
             st.rays_shadow += ns;
         }
-        const uint32_t n_next = S.host_counts[COUNT_ROW];
+        const uint32_t n_next = S.host_counts[1];
         if (n_next > S.n_active) return fail(TRT_EHIP, "internal error: queue grew");
         st.rays_indirect += n_next;
         S.n_active = n_next;
@@ -649,6 +663,7 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     HIPC(hipEventRecord(ev_end, stream));
     DeviceStats ds;
     HIPC(hipMemcpyAsync(&ds, d_stats, sizeof(ds), hipMemcpyDeviceToHost, stream));
+    if (accum_host) HIPC(hipMemcpyAsync(accum_host, d_acc, acc_bytes, hipMemcpyDeviceToHost, stream));
     HIPC(hipStreamSynchronize(stream));
     HIPC(hipGetLastError());
 
@@ -670,6 +685,28 @@ int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* 
     st.rows_rendered = rows.size();
     st.inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (uint32_t)sizeof(WideNode);
     if (stats_out) *stats_out = st;
+    return TRT_OK;
+}
+}  // namespace
+
+int trt_render_device(trt_handle* h, const trt_params* p, float* out_dev, void* hip_stream, trt_stats* stats_out)
+{
+    if (int e = checkParams(h, p)) return e;
+    return renderCore(h, p, 0u, (uint32_t)p->spp, out_dev, hip_stream, stats_out, nullptr);
+}
+
+int trt_render_samples(trt_handle* h, const trt_params* p, int32_t sample_begin, int32_t sample_end, double* accum_host, float* out_host, trt_stats* stats)
+{
+    if (int e = checkParams(h, p)) return e;
+    if (!accum_host) return fail(TRT_EINVAL, "null accumulator");
+    if (sample_begin < 0 || sample_end <= sample_begin || sample_end > p->spp) return fail(TRT_EINVAL, "sample range must satisfy 0 <= begin < end <= spp");
+    HIPC(hipSetDevice(h->device));
+    const int nrows = trt_rows_selected(p);
+    if (nrows < 1) return fail(TRT_EINVAL, "row interleave selects no rows of the tile");
+    const size_t bytes = (size_t)nrows * (size_t)(p->x1 - p->x0) * 3 * sizeof(float);
+    if (int e = h->out_buf.ensure(bytes)) return e;
+    if (int e = renderCore(h, p, (uint32_t)sample_begin, (uint32_t)sample_end, (float*)h->out_buf.p, nullptr, stats, accum_host)) return e;
+    if (out_host) HIPC(hipMemcpy(out_host, h->out_buf.p, bytes, hipMemcpyDeviceToHost));
     return TRT_OK;
 }
 

@@ -504,28 +504,30 @@ __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uin
     traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem);
 }
 
-// Block-wide stream compaction slot: every thread calls it; threads with `flag`
-// receive consecutive slots of the output queue.  Wave rank from
-// __ballot/popcount, wave offsets through LDS, ONE global atomic per block.
-// s_cnt must hold 2 * (NW + 1) words; `parity` alternates between calls so two
-// barriers per call suffice.
+// Block-wide stream compaction in two halves.  blockStage: every thread calls it with its `flag`; wave
+// ranks come from __ballot/popcount, wave totals go through LDS, and after ONE barrier thread 0 turns them
+// into exclusive offsets and issues the block's single atomicAdd on the queue counter — without waiting for
+// it.  The value it returns (`pend_base`, thread 0) is published in the NEXT call, before that call's
+// barrier, into the previous stage's buffer `pend_s`; after that barrier every thread reads its slot of the
+// previous stage as pend_s[NW] + pend_s[wave] + rank.  s_cnt holds three buffers of NW + 1 words, used in
+// turn (`parity` 0,1,2): a buffer is rewritten two barriers after its last reader.
 template <int BLOCK>
-__device__ inline uint32_t blockReserve(bool flag, uint32_t* counter, uint32_t* s_cnt, int parity)
+__device__ inline uint32_t* blockStage(bool flag, uint32_t* counter, uint32_t* s_cnt, int parity, uint32_t& rank, const uint32_t* pend_s, uint32_t& pend_base)
 {
     constexpr int NW = BLOCK / 64;
     uint32_t* s = s_cnt + parity * (NW + 1);
     const unsigned long long ballot = __ballot(flag);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+    rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
     if (lane == 0) s[wave] = (uint32_t)__popcll(ballot);
+    if (threadIdx.x == 0 && pend_s) const_cast<uint32_t*>(pend_s)[NW] = pend_base;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
         for (int w = 0; w < NW; ++w) { const uint32_t c = s[w]; s[w] = tot; tot += c; }
-        s[NW] = tot ? atomicAdd(counter, tot) : 0u;
+        pend_base = tot ? atomicAdd(counter, tot) : 0u;
     }
-    __syncthreads();
-    return s[NW] + s[wave] + rank;
+    return s;
 }
 
 // ---------------------------------------------------------------- K3 ----
@@ -539,7 +541,8 @@ struct ShadeArgs {
     RayQueue qout;
     ShadowQueue sq[TRT_MAX_LIGHTS];
     uint32_t* next_count;     // survivors -> qout
-    uint32_t* shadow_counts;  // [n_lights]
+    uint32_t* shadow_counts;  // light l: shadow_counts[l * shadow_count_stride]
+    uint32_t shadow_count_stride;
     f4* Lacc;
     TileDesc td;
     uint32_t s0;
@@ -556,7 +559,7 @@ constexpr uint32_t TRT_SHADE_LDS_TABLE_BYTES = 24 * 1024;
 
 __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
 {
-    __shared__ uint32_t s_cnt[2 * (TRT_SHADE_BLOCK / 64 + 1)];
+    __shared__ uint32_t s_cnt[3 * (TRT_SHADE_BLOCK / 64 + 1)];
     __shared__ uint32_t s_shaded, s_anyhit;
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[TRT_SHADE_LDS_TABLE_BYTES / 4];
     if (threadIdx.x == 0) { s_shaded = 0; s_anyhit = 0; }
@@ -606,27 +609,46 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         if ((threadIdx.x & 63u) == 0 && ok_ballot) atomicAdd(&s_shaded, (uint32_t)__popcll(ok_ballot));
         if (__ballot(c.had_hit) && (threadIdx.x & 63u) == 0) s_anyhit = 1;
 
-        // direct illumination: one shadow ray per light (pathTracing.cpp:34-74)
+        // Queue slots come from one atomicAdd per block and queue (blockStage), and that atomic's round trip
+        // is taken off the critical path: the rays of a stage are written one stage later, after the NEXT
+        // stage's compute and barrier, by when the base offset has long arrived.
+        //   stage l (one per light): NEE sample (pathTracing.cpp:34-74) -> shadow queue l
+        //   last stage: RR(0.8) then nextRay (pathTracing.cpp:78-99) -> next bounce's queue
+        uint32_t pend_base = 0;   // thread 0: value returned by the previous stage's atomic
+        const uint32_t* pend_s = nullptr;
+        bool pend_emit = false;
+        uint32_t pend_rank = 0, pend_li = 0;
+        f3 pend_wo = mk3(0, 0, 0), pend_w = mk3(0, 0, 0);
         for (uint32_t li = 0; li < sc.n_lights; ++li) {
             bool emit = false;
             f3 wo = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
             if (c.shade_ok) emit = lightSample(sc, c.vx, c.m, li, c.rng, wo, contrib);
-            const uint32_t slot = blockReserve<TRT_SHADE_BLOCK>(emit, A.shadow_counts + li, s_cnt, parity);
-            parity ^= 1;
-            if (emit) {
-                const f3 w = c.beta * contrib;
-                A.sq[li].sa[slot] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, wo.x);  // Q6: origin = hit point, no offset
-                A.sq[li].sb[slot] = mk4(wo.y, wo.z, u2f(c.pid), 0.0f);
-                A.sq[li].sw[slot] = mk4(w.x, w.y, w.z, 0.0f);
+            uint32_t rank;
+            uint32_t* s = blockStage<TRT_SHADE_BLOCK>(emit, A.shadow_counts + (size_t)li * A.shadow_count_stride, s_cnt, parity, rank, pend_s, pend_base);
+            parity = parity == 2 ? 0 : parity + 1;
+            if (pend_emit) {
+                const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
+                A.sq[pend_li].sa[slot] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, pend_wo.x);  // Q6: origin = hit point, no offset
+                A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), 0.0f);
+                A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
             }
+            pend_s = s; pend_emit = emit; pend_rank = rank; pend_li = li; pend_wo = wo; pend_w = c.beta * contrib;
         }
-
-        // indirect illumination: RR(0.8) then nextRay (pathTracing.cpp:78-99)
         f4 nra, nrb, nbt;
         const bool emit_next = shadeNext(c, A.max_depth, nra, nrb, nbt);
-        const uint32_t slot = blockReserve<TRT_SHADE_BLOCK>(emit_next, A.next_count, s_cnt, parity);
-        parity ^= 1;
+        uint32_t rank_next;
+        uint32_t* s_next = blockStage<TRT_SHADE_BLOCK>(emit_next, A.next_count, s_cnt, parity, rank_next, pend_s, pend_base);
+        parity = parity == 2 ? 0 : parity + 1;
+        if (pend_emit) {
+            const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
+            A.sq[pend_li].sa[slot] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, pend_wo.x);
+            A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), 0.0f);
+            A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
+        }
+        if (threadIdx.x == 0) s_next[TRT_SHADE_BLOCK / 64] = pend_base;  // publish the last base
+        __syncthreads();
         if (emit_next) {
+            const uint32_t slot = s_next[TRT_SHADE_BLOCK / 64] + s_next[threadIdx.x >> 6] + rank_next;
             A.qout.ra[slot] = nra;
             A.qout.rb[slot] = nrb;
             A.qout.bt[slot] = nbt;

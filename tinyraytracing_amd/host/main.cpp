@@ -18,7 +18,10 @@ static void usage()
 {
     std::fprintf(stderr,
                  "usage: tinyrt <basedir> <mtl> <xml> <obj> <spp> [--width W --height H] [--seed S] [--device D]\n"
-                 "              [--leaf N] [--max-depth D] [--out file.png]\n");
+                 "              [--leaf N] [--max-depth D] [--out file.png]\n"
+                 "              [--every N] [--checkpoint file.acc] [--stop-after M]\n"
+                 "                                                    progressive: N samples per step, image rewritten after\n"
+                 "                                                    every step, accumulator kept in file.acc (resumes from it)\n");
 }
 
 int main(int argc, char** argv)
@@ -42,6 +45,9 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--leaf")) opts.leaf_num = std::atoi(need("--leaf"));
         else if (!std::strcmp(argv[i], "--max-depth")) opts.max_depth = std::atoi(need("--max-depth"));
         else if (!std::strcmp(argv[i], "--out")) out_path = need("--out");
+        else if (!std::strcmp(argv[i], "--every")) opts.every = std::atoi(need("--every"));
+        else if (!std::strcmp(argv[i], "--checkpoint")) opts.checkpoint = need("--checkpoint");
+        else if (!std::strcmp(argv[i], "--stop-after")) opts.stop_after = std::atoi(need("--stop-after"));
         else { usage(); return 2; }
     }
     try {
@@ -57,6 +63,17 @@ int main(int argc, char** argv)
         scene.camera.Print();
         std::vector<double> image((size_t)scene.img_width * scene.img_height * 3, 0.0);
         trt_stats st{};
+        if (opts.every > 0 || !opts.checkpoint.empty()) {
+            // the picture so far after every step (what a viewer would poll), same file as the final one
+            const int w = scene.img_width, hgt = scene.img_height;
+            const std::string prog_path = out_path.empty() ? basedir + "/image" + std::to_string(opts.spp) + ".png" : out_path;
+            opts.on_progress = [w, hgt, prog_path, &opts](int done, const float* rgb) {
+                std::vector<uint8_t> bytes;
+                trt::tonemap(rgb, w, hgt, bytes);
+                if (!trt::writePNG(prog_path, w, hgt, bytes.data())) std::fprintf(stderr, "cannot write %s\n", prog_path.c_str());
+                std::fprintf(stderr, "\r%d / %d samples", done, opts.spp);
+            };
+        }
         trt::render(scene, opts, image.data(), &st);
         const uint64_t rays = st.rays_camera + st.rays_shadow + st.rays_indirect;
         std::printf("rays: %llu (camera %llu, shadow %llu, indirect %llu)  render %.3f ms  %.1f Mrays/s\n", (unsigned long long)rays,

@@ -1,9 +1,53 @@
 #include "render.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <vector>
 
 namespace trt {
+
+namespace {
+const char CKPT_MAGIC[8] = {'T', 'R', 'T', 'A', 'C', 'C', '1', 0};
+struct CkptHead {
+    char magic[8];
+    int32_t width, height, spp, samples_done, max_depth;
+    uint32_t seed;
+    uint64_t n_doubles;
+};
+}  // namespace
+
+bool readCheckpoint(const std::string& path, Checkpoint& head, std::vector<double>& accum)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    CkptHead h;
+    const bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, CKPT_MAGIC, 8) == 0 && h.width > 0 && h.height > 0 &&
+                    h.n_doubles == (uint64_t)h.width * (uint64_t)h.height * 3 && h.samples_done >= 0 && h.samples_done <= h.spp;
+    if (ok) {
+        accum.resize(h.n_doubles);
+        if (std::fread(accum.data(), sizeof(double), accum.size(), f) != accum.size()) { std::fclose(f); throw std::runtime_error("checkpoint " + path + ": truncated"); }
+    }
+    std::fclose(f);
+    if (!ok) throw std::runtime_error("checkpoint " + path + ": not an accumulator file of this program");
+    head.width = h.width; head.height = h.height; head.spp = h.spp; head.samples_done = h.samples_done; head.max_depth = h.max_depth; head.seed = h.seed;
+    return true;
+}
+
+void writeCheckpoint(const std::string& path, const Checkpoint& head, const std::vector<double>& accum)
+{
+    const std::string tmp = path + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + tmp);
+    CkptHead h;
+    std::memcpy(h.magic, CKPT_MAGIC, 8);
+    h.width = head.width; h.height = head.height; h.spp = head.spp; h.samples_done = head.samples_done; h.max_depth = head.max_depth; h.seed = head.seed;
+    h.n_doubles = accum.size();
+    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(accum.data(), sizeof(double), accum.size(), f) == accum.size();
+    if (std::fclose(f) != 0 || !ok) throw std::runtime_error("cannot write " + tmp);
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp + " to " + path);
+}
 
 void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stats)
 {
@@ -24,8 +68,52 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
     p.flags = (opts.timing ? TRT_FLAG_TIMING : 0u) | (opts.overlap ? TRT_FLAG_OVERLAP : 0u);
     p.mem_budget = opts.mem_budget;
     std::vector<float> out((size_t)p.width * p.height * 3);
-    const int rc = trt_render(h, &p, out.data(), stats);
-    const std::string msg = rc ? trt_last_error() : "";
+    int rc = TRT_OK;
+    std::string msg;
+    if (opts.every <= 0 && opts.checkpoint.empty() && !opts.on_progress && opts.stop_after <= 0) {
+        rc = trt_render(h, &p, out.data(), stats);
+        if (rc) msg = trt_last_error();
+    } else {
+        // progressive: the accumulator lives on the host between calls (and in the checkpoint file)
+        std::vector<double> accum(out.size(), 0.0);
+        int done = 0;
+        try {
+            Checkpoint ck;
+            std::vector<double> saved;
+            if (!opts.checkpoint.empty() && readCheckpoint(opts.checkpoint, ck, saved)) {
+                if (ck.width != p.width || ck.height != p.height || ck.spp != p.spp || ck.seed != p.seed || ck.max_depth != p.max_depth)
+                    throw std::runtime_error("checkpoint " + opts.checkpoint + " belongs to another render (size, spp, seed or max depth differ)");
+                accum.swap(saved);
+                done = ck.samples_done;
+            }
+            if (stats) std::memset(stats, 0, sizeof(*stats));
+            const int step = opts.every > 0 ? opts.every : p.spp;
+            for (size_t i = 0; i < out.size(); ++i) out[i] = (float)accum[i];  // the picture the checkpoint holds (k_finalize's rounding)
+            while (done < p.spp && rc == TRT_OK && !(opts.stop_after > 0 && done >= opts.stop_after)) {
+                const int end = std::min(p.spp, done + step);
+                trt_stats st;
+                rc = trt_render_samples(h, &p, done, end, accum.data(), out.data(), &st);
+                if (rc) { msg = trt_last_error(); break; }
+                done = end;
+                if (stats) {
+                    stats->rays_camera += st.rays_camera; stats->rays_shadow += st.rays_shadow; stats->rays_indirect += st.rays_indirect;
+                    stats->shaded_hits += st.shaded_hits; stats->render_ms += st.render_ms; stats->passes += st.passes;
+                    stats->max_bounces = std::max(stats->max_bounces, st.max_bounces); stats->rows_rendered = st.rows_rendered;
+                    stats->inner_node_bytes = st.inner_node_bytes;
+                    for (int k = 0; k < TRT_MAX_KERNELS; ++k) { stats->launches[k] += st.launches[k]; stats->kernel_ms[k] += st.kernel_ms[k]; }
+                }
+                if (!opts.checkpoint.empty()) {
+                    Checkpoint w;
+                    w.width = p.width; w.height = p.height; w.spp = p.spp; w.samples_done = done; w.max_depth = p.max_depth; w.seed = p.seed;
+                    writeCheckpoint(opts.checkpoint, w, accum);
+                }
+                if (opts.on_progress) opts.on_progress(done, out.data());
+            }
+        } catch (...) {
+            trt_destroy(h);
+            throw;
+        }
+    }
     trt_destroy(h);
     if (rc != TRT_OK) throw std::runtime_error("trt_render: " + msg);
     for (size_t i = 0; i < out.size(); ++i) image[i] += (double)out[i];

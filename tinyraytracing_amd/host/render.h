@@ -3,7 +3,9 @@
 // the sample/pixel loop on the GPU through the C-ABI (include/trt.h).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
+#include <vector>
 
 #include "scene.h"
 #include "trt.h"
@@ -20,7 +22,22 @@ struct RenderOpts {
     uint64_t mem_budget = 0;
     bool timing = false;
     bool overlap = true;      // two sample passes in flight (TRT_FLAG_OVERLAP)
+    // Progressive output (trt_render_samples): render `every` samples per call (0 = all in one call), hand the
+    // image so far to `on_progress`, and keep the accumulator in `checkpoint` (written after every call, atomically;
+    // read at start: a file that matches width/height/spp/seed/max_depth resumes where it stopped).
+    int every = 0;
+    int stop_after = 0;       // > 0: return once this many samples are done (a time-boxed run; resume from the checkpoint later)
+    std::string checkpoint;
+    std::function<void(int samples_done, const float* rgb)> on_progress;
 };
+
+// Accumulator file of a progressive render: header + width*height*3 doubles (the sums of trt_render_samples).
+struct Checkpoint {
+    int32_t width = 0, height = 0, spp = 0, samples_done = 0, max_depth = 0;
+    uint32_t seed = 0;
+};
+bool readCheckpoint(const std::string& path, Checkpoint& head, std::vector<double>& accum);   // false: no such file
+void writeCheckpoint(const std::string& path, const Checkpoint& head, const std::vector<double>& accum);
 
 // image: img_width*img_height*3 doubles, zero-initialised by the caller like
 // main.cpp:74-75; the averaged linear radiance is ADDED to it (main.cpp:103-108).
