@@ -132,6 +132,20 @@ def main():
             launches[k] += st.launches[k]
     sync()
     elapsed = time.perf_counter() - t_begin
+    # beside the contract's number: the same steps with two sample passes in flight (TRT_FLAG_OVERLAP, what
+    # render()/tinyrt use).  Not `value`: per-kernel hipEvent times of overlapping passes contain each other.
+    overlap_extra = None
+    if world == 1 and not a.overlap:
+        p_ov = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_OVERLAP, mem_budget=budget)
+        step(p_ov)
+        sync()
+        t_ov = time.perf_counter()
+        rays_ov = 0
+        for _ in range(a.steps):
+            rays_ov += step(p_ov)[1].rays
+        sync()
+        t_ov = time.perf_counter() - t_ov
+        overlap_extra = {"value": round(rays_ov / t_ov / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(t_ov / a.steps * 1e3, 3)}
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -184,7 +198,7 @@ def main():
                 "visits_per_ray": round((st_count.inner_visits[0] + st_count.inner_visits[1]) / max(st_count.rays, 1), 2),
                 "tri_tests_per_ray": round((st_count.tri_tests[0] + st_count.tri_tests[1]) / max(st_count.rays, 1), 2)},
             "roofline": roofline, "kernels_rank0": kernels, "passes": st.passes, "max_path_vertices": st.max_bounces + 1,
-            "scene_load_build_s": round(t_load, 2),
+            "scene_load_build_s": round(t_load, 2), "with_pass_overlap": overlap_extra,
         }
         if a.save_png and img is not None:
             T.imshow(img.cpu().numpy(), a.save_png)

@@ -14,7 +14,7 @@ using namespace trtd;
 
 namespace {
 struct ArrayStack {
-    uint32_t s[320];
+    uint32_t s[1024];
     void push(int sp, uint32_t v) { s[sp] = v; }
     uint32_t pop(int sp) const { return s[sp]; }
 };

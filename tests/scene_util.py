@@ -62,3 +62,33 @@ def quad(x0, x1, y0, y1, z, vbase, nz=1.0):
     b = vbase
     faces = [f"f {b}/1/{{n}} {b+1}/1/{{n}} {b+2}/1/{{n}}", f"f {b}/1/{{n}} {b+2}/1/{{n}} {b+3}/1/{{n}}"]
     return lines, faces, vbase + 4
+
+
+def shrink_some_boxes(scene, n, seed=3, amount=0.35):
+    """Makes the BVH 'foreign': pulls in the stored box of `n` random inner-node children so that it no
+    longer contains the boxes of its own children (a tree no builder of this repo emits, but one the C-ABI
+    accepts).  The reference semantics stay well defined — a subtree is entered iff the ray passes that
+    box — so oracle and library must still agree.  Mutates scene.flat in place; use a private Scene."""
+    import numpy as np
+    f = scene.flat.contents
+    rng = np.random.default_rng(seed)
+    changed = 0
+    for k in rng.permutation(f.n_nodes)[: 4 * n]:
+        node = f.nodes[int(k)]
+        c = int(rng.integers(0, 2))
+        ref = node.child0 if c == 0 else node.child1
+        if ref & 0x80000000:
+            continue  # only boxes of inner children
+        lo, hi = (node.lo0, node.hi0) if c == 0 else (node.lo1, node.hi1)
+        a = int(rng.integers(0, 3))
+        ext = hi[a] - lo[a]
+        if ext <= 0:
+            continue
+        if rng.random() < 0.5:
+            lo[a] = lo[a] + amount * ext
+        else:
+            hi[a] = hi[a] - amount * ext
+        changed += 1
+        if changed >= n:
+            break
+    return changed

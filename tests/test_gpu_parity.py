@@ -66,6 +66,21 @@ def test_trace_degenerate_rays(name, renderer_factory):
     assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
 
 
+def test_trace_foreign_bvh_with_boxes_that_do_not_nest():
+    """A tree whose stored boxes do not contain their children's (legal through the C-ABI): the wide collapse must
+    keep those nodes, and the hits must equal the oracle's."""
+    import scene_util
+    s = T.Scene.named("staircase", 64, 36)
+    assert scene_util.shrink_some_boxes(s, 400) == 400
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(100000, lo, hi, seed=8)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    r = T.Renderer(s, 0)
+    t1, tri1, uv1 = r.trace_closest(org, dirs)
+    r.close()
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+
+
 def test_trace_soup_deep_bvh(renderer_factory):
     s = get_scene("soup", 64, 36, n=200000)
     assert s.arrays()["bvh_depth"] > 12

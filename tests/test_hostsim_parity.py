@@ -62,6 +62,23 @@ def test_wide_tree_on_degenerate_rays(name):
     assert (tri0 >= 0).sum() > 1000
 
 
+def test_foreign_bvh_with_boxes_that_do_not_nest():
+    """collapseBvh (trt_wide.h) may only drop an intermediate box that contains its children's boxes; where a
+    foreign tree breaks that, the node must stay a node of its own and the hits must still equal the oracle's
+    (which enters a subtree iff the ray passes its stored box, bvh.cpp:162-166)."""
+    import scene_util
+    s = T.Scene.named("staircase", 64, 36)
+    assert scene_util.shrink_some_boxes(s, 400) == 400
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(30000, lo, hi, seed=8)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    t1, tri1, uv1, _ = H.trace(s.flat, org, dirs)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+    # and the shrunken boxes do change what is found (the test bites)
+    t2, tri2, _ = O.trace(get_scene("staircase", 64, 36).flat, org, dirs)
+    assert (tri0 != tri2).sum() > 50
+
+
 def test_device_code_on_synthetic_soup_and_tiles():
     s = T.Scene.named("soup", 48, 27, n=20000)
     p = T.make_params(48, 27, 4, T.SEED_SOUP)
