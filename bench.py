@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--overlap", action="store_true", help="TRT_FLAG_OVERLAP: two passes in flight (+4-5 %% Mrays/s; per-kernel timings then overlap)")
+    ap.add_argument("--also-overlap", action="store_true", help="after the timed steps, time the same steps again with TRT_FLAG_OVERLAP and report it as with_pass_overlap")
     ap.add_argument("--save-png", default=None)
     return ap.parse_args()
 
@@ -132,10 +133,11 @@ def main():
             launches[k] += st.launches[k]
     sync()
     elapsed = time.perf_counter() - t_begin
-    # beside the contract's number: the same steps with two sample passes in flight (TRT_FLAG_OVERLAP, what
-    # render()/tinyrt use).  Not `value`: per-kernel hipEvent times of overlapping passes contain each other.
+    # --also-overlap: beside the contract's number, the same steps with two sample passes in flight
+    # (TRT_FLAG_OVERLAP, what render()/tinyrt use).  Not `value`: per-kernel hipEvent times of overlapping passes
+    # contain each other.  Off by default so that a rocprofv3 run of the default command sees the timed launches only.
     overlap_extra = None
-    if world == 1 and not a.overlap:
+    if world == 1 and not a.overlap and a.also_overlap:
         p_ov = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_OVERLAP, mem_budget=budget)
         step(p_ov)
         sync()

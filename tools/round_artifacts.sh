@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 tools/prof.sh ${r}_back --steps 3 --warmup 1 > gpurun_out/prof_${r}_back.log 2>&1
 echo "prof done"
-python bench.py > gpurun_out/${r}_bench_back.json 2> gpurun_out/${r}_bench_back.err
+python bench.py --also-overlap > gpurun_out/${r}_bench_back.json 2> gpurun_out/${r}_bench_back.err
 echo "back done"
 python bench.py --overlap --no-cpu-baseline > gpurun_out/${r}_bench_back_overlap.json 2>/dev/null
 python bench.py --scene veach-mis --no-cpu-baseline > gpurun_out/${r}_bench_veach.json 2>/dev/null
