@@ -127,7 +127,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
                 if (cx.add_L) L = L + cx.addL;
                 for (uint32_t li = 0; li < hs.sc.n_lights; ++li) {
                     f3 wo, contrib;
-                    if (!cx.shade_ok || !lightSample(hs.sc, cx.vx, cx.m, li, cx.rng, wo, contrib)) continue;
+                    if (!cx.shade_ok || !lightSample(hs.sc, cx.vx, *cx.m, li, cx.rng, wo, contrib)) continue;
                     const f3 w = cx.beta * contrib;
                     r_sh++;
                     // k_trace_shadow

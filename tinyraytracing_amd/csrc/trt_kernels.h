@@ -622,7 +622,7 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         for (uint32_t li = 0; li < sc.n_lights; ++li) {
             bool emit = false;
             f3 wo = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
-            if (c.shade_ok) emit = lightSample(sc, c.vx, c.m, li, c.rng, wo, contrib);
+            if (c.shade_ok) emit = lightSample(sc, c.vx, *c.m, li, c.rng, wo, contrib);
             uint32_t rank;
             uint32_t* s = blockStage<TRT_SHADE_BLOCK>(emit, A.shadow_counts + (size_t)li * A.shadow_count_stride, s_cnt, parity, rank, pend_s, pend_base);
             parity = parity == 2 ? 0 : parity + 1;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
             if (c.shade_ok) n_shaded++;
             for (uint32_t li = 0; li < sc.n_lights; ++li) {
                 f3 wo, contrib;
-                if (!c.shade_ok || !lightSample(sc, c.vx, c.m, li, c.rng, wo, contrib)) continue;
+                if (!c.shade_ok || !lightSample(sc, c.vx, *c.m, li, c.rng, wo, contrib)) continue;
                 const f3 w = c.beta * contrib;
                 n_shadow++;
                 const Hit sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1]);

@@ -80,9 +80,16 @@ struct alignas(16) MaterialDev {
     float radiance[3];
     int32_t is_emissive;
     int32_t tex;  // -1 = none
-    int32_t pad[4];
+    // Values shade() recomputes at every vertex although they depend on the material alone; formed once here
+    // by the very operations of the per-vertex code (IEEE division / square root: same bits on host and device):
+    float Kd_pi[3];   // Kd / pi                      (pathTracing.cpp:67, untextured materials)
+    float sel_kd;     // |Kd| / (|Kd| + |Ks|)          (lobe selection, pathTracing.cpp:188-191)
+    float sel_kdks;   // sel_kd + |Ks| / (|Kd| + |Ks|)
+    float rf0;        // ((n1 - n2) / (n1 + n2))^2     (Schlick, pathTracing.cpp:157-160; the same either way)
+    float Ni_inv;     // 1 / Ni
+    int32_t pad;
 };
-static_assert(sizeof(MaterialDev) == 80, "MaterialDev must be five 16-byte words");
+static_assert(sizeof(MaterialDev) == 96, "MaterialDev must be six 16-byte words");
 // trt_light_tri (19 floats) padded to 80 B
 struct alignas(16) LightTriDev {
     float v[3][3];
@@ -97,7 +104,7 @@ struct alignas(16) LightDev {
     float radiance[3];
     float area;
     uint32_t tri_first, tri_count;
-    uint32_t pad;
+    float pdf;  // 1 / area (pathTracing.cpp:63), formed once
 };
 static_assert(sizeof(LightDev) == 32, "LightDev must be two 16-byte words");
 struct TextureDev {
@@ -145,7 +152,15 @@ TRT_HD inline MaterialDev makeMaterialDev(const trt_material& m)
     for (int k = 0; k < 3; ++k) { d.Kd[k] = m.Kd[k]; d.Ks[k] = m.Ks[k]; d.Tr[k] = m.Tr[k]; d.radiance[k] = m.radiance[k]; }
     d.Ns = m.Ns; d.Ni = m.Ni;
     d.is_emissive = m.is_emissive; d.tex = m.tex;
-    d.pad[0] = d.pad[1] = d.pad[2] = d.pad[3] = 0;
+    for (int k = 0; k < 3; ++k) d.Kd_pi[k] = m.Kd[k] / TRT_PI;
+    const float Kd_len = length(ld3(m.Kd)), Ks_len = length(ld3(m.Ks));
+    const float kd = Kd_len / (Kd_len + Ks_len), ks = Ks_len / (Kd_len + Ks_len);
+    d.sel_kd = kd;
+    d.sel_kdks = kd + ks;
+    const float q = (1.0f - m.Ni) / (1.0f + m.Ni);  // (Ni - 1) / (Ni + 1) is its exact negative: one square serves both sides
+    d.rf0 = q * q;
+    d.Ni_inv = 1.0f / m.Ni;
+    d.pad = 0;
     return d;
 }
 TRT_HD inline LightTriDev makeLightTriDev(const trt_light_tri& t)
@@ -162,7 +177,7 @@ TRT_HD inline LightDev makeLightDev(const trt_light& l)
     LightDev d;
     d.mat = l.mat;
     for (int k = 0; k < 3; ++k) d.radiance[k] = l.radiance[k];
-    d.area = l.area; d.tri_first = l.tri_first; d.tri_count = l.tri_count; d.pad = 0;
+    d.area = l.area; d.tri_first = l.tri_first; d.tri_count = l.tri_count; d.pdf = 1.0f / l.area;
     return d;
 }
 
@@ -428,30 +443,28 @@ TRT_HD inline int nextRay(const MaterialDev& m, f3 pn, f3 I, Stream& rng, f3& ou
     if (m.Ni > 1.0f) {
         const float cos_in = dot(I, pn);
         f3 n;
-        float n1, n2;
-        if (cos_in > 0.0f) { n = -pn; n1 = m.Ni; n2 = 1.0f; }
-        else { n = pn; n1 = 1.0f; n2 = m.Ni; }
-        const float q = (n1 - n2) / (n1 + n2);
-        const float rf0 = q * q;
+        float eta;  // n1 / n2
+        if (cos_in > 0.0f) { n = -pn; eta = m.Ni; }         // n1 = Ni, n2 = 1:  Ni / 1 == Ni
+        else { n = pn; eta = m.Ni_inv; }                    // n1 = 1, n2 = Ni
+        const float rf0 = m.rf0;  // ((n1 - n2) / (n1 + n2))^2, makeMaterialDev
         const float x = 1.0f - fabsf(cos_in);
         const float x2 = x * x;
         const float fresnel = rf0 + (1.0f - rf0) * ((x2 * x2) * x);
         if (fresnel < rng.next()) {
-            const f3 T = refract(I, n, n1 / n2);
+            const f3 T = refract(I, n, eta);
             if (T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) { out = T; return TRT_RAY_TRANSMISSION; }
             out = reflect(I, n);
             return TRT_RAY_SPECULAR;
         }
     }
-    const float Kd_len = length(ld3(m.Kd)), Ks_len = length(ld3(m.Ks));
-    const float kd = Kd_len / (Kd_len + Ks_len), ks = Ks_len / (Kd_len + Ks_len);
+    const float kd = m.sel_kd, kdks = m.sel_kdks;  // |Kd| / (|Kd| + |Ks|) and that + |Ks| / (|Kd| + |Ks|), makeMaterialDev
     const float p = rng.next();
     if (p < kd) {
         const float u_phi = rng.next(), u_theta = rng.next();
         out = sampleDir(pn, TRT_RAY_DIFFUSE, m.Ns, u_phi, u_theta);
         return TRT_RAY_DIFFUSE;
     }
-    if (m.Ns > 1.0f && p < kd + ks) {
+    if (m.Ns > 1.0f && p < kdks) {
         const float u_phi = rng.next(), u_theta = rng.next();
         out = sampleDir(reflect(I, pn), TRT_RAY_SPECULAR, m.Ns, u_phi, u_theta);
         return TRT_RAY_SPECULAR;
@@ -530,7 +543,7 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
     wo = normalize(diff);
     const float cos_s = dot(wo, vx.pn);
     if (!(cos_s > 0.0f)) return false;  // pathTracing.cpp:60: such a sample never contributes
-    const float pdf_light = 1.0f / L.area;
+    const float pdf_light = L.pdf;  // 1 / area, makeLightDev
     const float cos_theta_p = fabsf(dot(wo, light_n));
     const float cos_theta = fabsf(cos_s / length(vx.pn));
     const f3 radiance = ld3(L.radiance);
@@ -540,7 +553,7 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
     const float cos_alpha = ca > 0.0f ? ca : 0.0f;
     const float pw = trt_pow01(cos_alpha, m.Ns);
     const f3 spec = ((ld3(m.Ks) * (m.Ns + 2.0f)) * pw) / (2.0f * TRT_PI);
-    const f3 brdf = vx.Kd / TRT_PI + spec;
+    const f3 brdf = (m.tex >= 0 ? vx.Kd / TRT_PI : ld3(m.Kd_pi)) + spec;
     contrib = intensity * brdf;
     return true;
 }
@@ -599,7 +612,7 @@ struct ShadeCtx {
     f3 d, beta;
     uint32_t pid, depth;
     Vertex vx;
-    MaterialDev m;
+    const MaterialDev* m;  // into the scene's table (LDS copy inside k_shade): fields are fetched where they are used, not held in registers
     Stream rng;
 };
 
@@ -613,7 +626,7 @@ TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s
     c.pid = 0; c.depth = 0;
     c.vx.P = c.vx.pn = c.vx.wi = c.vx.Kd = mk3(0, 0, 0);
     c.vx.mat = 0;
-    c.m.Ns = 1.0f; c.m.Ni = 1.0f; c.m.tex = -1; c.m.is_emissive = 0;
+    c.m = sc.materials;  // any valid record: only dereferenced under had_hit
     c.rng.key.k0 = c.rng.key.k1 = 0; c.rng.ctr = 0;
     Hit h;
     h.t = hit4.x; h.tri = (int32_t)f2u(hit4.y); h.u = hit4.z; h.v = hit4.w; h.flags = 0;
@@ -626,20 +639,20 @@ TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s
     const uint32_t meta = f2u(rb.w);
     c.depth = metaDepth(meta);
     const TriShade ts = sc.tri_shade[h.tri];
-    c.m = sc.materials[ts.mat];
-    if (c.m.is_emissive) {
+    c.m = sc.materials + ts.mat;
+    if (c.m->is_emissive) {
         // pathTracing.cpp:9-12 returns the radiance; the callers keep it for the camera ray
         // (main.cpp:101) and for TRANSMISSION (pathTracing.cpp:95-96), not after DIFFUSE/SPECULAR (Q9)
         const uint32_t type = metaType(meta);
         if (c.depth == 0 || type == TRT_RAY_TRANSMISSION) {
-            const f3 rad = ld3(c.m.radiance);
+            const f3 rad = ld3(c.m->radiance);
             c.add_L = true;
             c.addL = c.depth == 0 ? rad : c.beta * rad;
         }
         return;
     }
     c.shade_ok = true;
-    c.vx = makeVertex(sc, h, o, c.d, ts, c.m);
+    c.vx = makeVertex(sc, h, o, c.d, ts, *c.m);
     c.rng.key = pathKey(td, s0, c.pid);
     c.rng.ctr = metaCtr(meta);
 }
@@ -652,9 +665,9 @@ TRT_HD inline bool shadeNext(ShadeCtx& c, int max_depth, f4& ra, f4& rb, f4& bt)
     const bool last = (max_depth > 0 && (int)c.depth + 1 >= max_depth) || c.depth + 1 >= TRT_MAX_PATH_DEPTH;
     if (last || !(c.rng.next() < TRT_P_RR)) return false;  // RR, pathTracing.cpp:104-109
     f3 nd;
-    const int type = nextRay(c.m, c.vx.pn, c.d, c.rng, nd);
+    const int type = nextRay(*c.m, c.vx.pn, c.d, c.rng, nd);
     if (type == TRT_RAY_INVALID) return false;
-    const f3 w = (type == TRT_RAY_TRANSMISSION) ? ld3(c.m.Tr) : c.vx.Kd;  // Q8: SPECULAR is weighted by Kd too
+    const f3 w = (type == TRT_RAY_TRANSMISSION) ? ld3(c.m->Tr) : c.vx.Kd;  // Q8: SPECULAR is weighted by Kd too
     const f3 nb = (c.beta * w) / TRT_P_RR;
     ra = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, nd.x);  // Q6: origin = hit point, no offset
     rb = mk4(nd.y, nd.z, u2f(c.pid), u2f(packMeta(c.rng.ctr, (uint32_t)type, c.depth + 1)));
