@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--overlap", action="store_true", help="TRT_FLAG_OVERLAP: two passes in flight (+4-5 %% Mrays/s; per-kernel timings then overlap)")
+    ap.add_argument("--fixed-nee", action="store_true", help="TRT_FLAG_FIXED_NEE: unbiased light sampling + occlusion-test shadow rays (not the parity mode; not the headline)")
     ap.add_argument("--also-overlap", action="store_true", help="after the timed steps, time the same steps again with TRT_FLAG_OVERLAP and report it as with_pass_overlap")
     ap.add_argument("--save-png", default=None)
     return ap.parse_args()
@@ -92,9 +93,9 @@ def main():
     renderer = T.Renderer(scene, local_rank)
     budget = int(a.mem_gb * (1 << 30))
 
-    ov = T.TRT_FLAG_OVERLAP if a.overlap else 0
+    ov = (T.TRT_FLAG_OVERLAP if a.overlap else 0) | (T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0)
     p_time = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_TIMING | ov, mem_budget=budget)
-    p_count = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_TIMING | T.TRT_FLAG_COUNT, mem_budget=budget)
+    p_count = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_TIMING | T.TRT_FLAG_COUNT | (T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0), mem_budget=budget)
     nrows = len(T.rows_selected(p_time))
     out = torch.empty((nrows, a.width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
@@ -138,7 +139,7 @@ def main():
     # contain each other.  Off by default so that a rocprofv3 run of the default command sees the timed launches only.
     overlap_extra = None
     if world == 1 and not a.overlap and a.also_overlap:
-        p_ov = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_OVERLAP, mem_budget=budget)
+        p_ov = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_OVERLAP | (T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0), mem_budget=budget)
         step(p_ov)
         sync()
         t_ov = time.perf_counter()
@@ -189,7 +190,7 @@ def main():
             "dtype": "f32", "data": f"scene '{a.scene}' ({WORKLOADS[a.scene]}), counter RNG seed {seed:#x}",
             "config": {"workload": f"{WORKLOADS[a.scene]}, {a.width}x{a.height}, {a.spp} spp", "scene": a.scene, "width": a.width,
                        "height": a.height, "spp": a.spp, "triangles": scene.info["n_triangles"], "bvh_nodes": scene.arrays()["n_nodes"],
-                       "leaf_num": a.leaf if a.leaf is not None else (T.TINY_LEAF if scene.info["n_triangles"] <= 64 else T.DEFAULT_LEAF), "overlap_passes": bool(a.overlap), "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
+                       "leaf_num": a.leaf if a.leaf is not None else (T.TINY_LEAF if scene.info["n_triangles"] <= 64 else T.DEFAULT_LEAF), "overlap_passes": bool(a.overlap), "fixed_nee": bool(a.fixed_nee), "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
             "rays_per_step": rays_total // a.steps,
             "rays_rank0": {"camera": st.rays_camera, "shadow": st.rays_shadow, "indirect": st.rays_indirect},
             "device_render_ms_per_step_rank0": round(render_ms / a.steps, 3),
@@ -222,11 +223,12 @@ def cpu_baseline(a, scene, seed):
     import oracle_lib as O
     import tinyraytracing_amd as T
     threads = len(os.sched_getaffinity(0))
-    p1 = T.make_params(a.width, a.height, 1, seed)
+    fx = T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0
+    p1 = T.make_params(a.width, a.height, 1, seed, flags=fx)
     _, s1 = O.render(scene.flat, p1, threads=threads)
     spp = int(max(1, min(a.spp, a.cpu_seconds / max(s1.seconds, 1e-3))))
     if spp > 1:
-        _, s = O.render(scene.flat, T.make_params(a.width, a.height, spp, seed), threads=threads)
+        _, s = O.render(scene.flat, T.make_params(a.width, a.height, spp, seed, flags=fx), threads=threads)
     else:
         s = s1
     return {"value": round(s.rays / s.seconds / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",

@@ -137,6 +137,10 @@ typedef struct trt_scene {
 #define TRT_FLAG_COUNT 2u    /* count inner-node visits / triangle tests (stats kernels) */
 #define TRT_FLAG_OVERLAP 4u  /* keep two sample passes in flight on two streams (+4-5 % throughput; per-kernel
                               * timings then include the other pass's kernels, so profiling runs leave it off) */
+#define TRT_FLAG_FIXED_NEE 8u /* opt out of the reference's next-event-estimation quirks: every light's CDF
+                              * draw spans that light's own area, light points are uniform on the chosen triangle, and the
+                              * shadow test is an occlusion test up to the light sample (any hit in [0.0005, 0.999 * distance)
+                              * blocks; a miss is visible) instead of closest-hit + material comparison.  Off = parity mode. */
 
 typedef struct trt_params {
     int32_t width, height;   /* full image size (scene.img_width/height, scene.cpp:13-14) */

@@ -208,6 +208,33 @@ struct Tracer {
         return r1.t < r2.t ? r1 : r2;
     }
 
+    // Occlusion test of TRT_FLAG_FIXED_NEE: does anything lie in front of t_max?  Same visit set as traverse().
+    bool anyBefore(uint32_t ref, V3 o, V3 d, V3 inv, float t_max) const
+    {
+        if (ref & TRT_LEAF_BIT) {
+            bool found = false;
+            for (uint32_t i = TRT_LEAF_FIRST(ref); i < TRT_LEAF_FIRST(ref) + TRT_LEAF_COUNT(ref); ++i) {
+                float t, u, v;
+                if (cnt) cnt->tests[kind]++;
+                if (triTest(sv.tris[i], o, d, t, u, v) && t < t_max) found = true;
+            }
+            return found;
+        }
+        const trt_bvh_node& n = sv.s->nodes[ref];
+        if (cnt) cnt->inner[kind]++;
+        const float d1 = aabb(n.lo0, n.hi0, o, inv);
+        const float d2 = aabb(n.lo1, n.hi1, o, inv);
+        bool found = false;
+        if (d1 > 0) found = anyBefore(n.child0, o, d, inv, t_max);
+        if (d2 > 0) found = anyBefore(n.child1, o, d, inv, t_max) || found;
+        return found;
+    }
+    bool occluded(V3 o, V3 d, float t_max) const
+    {
+        const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        return anyBefore(0u, o, d, inv, t_max);
+    }
+
     Hit closest(V3 o, V3 d) const
     {
         const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -333,19 +360,27 @@ struct PathTracer {
 
     // One light of the NEE loop (pathTracing.cpp:34-74).  Returns true and the
     // unweighted contribution when the sample is visible and front-facing.
+    bool fixed_nee = false;  // TRT_FLAG_FIXED_NEE: opt out of Q3 / Q4 / Q5 (include/trt.h)
+
     bool lightSample(const Vertex& vx, uint32_t li, Stream& rng, V3& contrib)
     {
         const trt_scene* s = sv.s;
         const trt_light& L = s->lights[li];
         // Q3: the CDF draw always spans the FIRST light's area (static u1, pathTracing.cpp:38)
-        const float rnd = rng.next() * s->lights[0].area;
+        const float rnd = rng.next() * (fixed_nee ? L.area : s->lights[0].area);
         const trt_light_tri* lt = nullptr;
         for (uint32_t k = 0; k < L.tri_count; ++k)
             if (rnd < s->light_tris[L.tri_first + k].cum_area) { lt = &s->light_tris[L.tri_first + k]; break; }
         if (!lt) return false;
         const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
-        const float rs = (r1 + r2) + r3;
-        const float p1 = r1 / rs, p2 = r2 / rs, p3 = r3 / rs;
+        float p1, p2, p3;
+        if (fixed_nee) {  // uniform on the triangle (r3 drawn, unused)
+            const float su = sqrtf(r1);
+            p1 = 1.0f - su; p2 = su * (1.0f - r2); p3 = su * r2;
+        } else {  // Q4
+            const float rs = (r1 + r2) + r3;
+            p1 = r1 / rs; p2 = r2 / rs; p3 = r3 / rs;
+        }
         const V3 light_p = (ld(lt->v[0]) * p1 + ld(lt->v[1]) * p2) + ld(lt->v[2]) * p3;
         const V3 light_n = normalize((ld(lt->vn[0]) * p1 + ld(lt->vn[1]) * p2) + ld(lt->vn[2]) * p3);
         const V3 diff = light_p - vx.P;
@@ -353,9 +388,13 @@ struct PathTracer {
         const float cos_s = dot(wo, vx.pn);
         if (!(cos_s > 0.0f)) return false;  // the reference traces and then discards (pathTracing.cpp:60)
         cnt.rays[1]++;
-        const Hit h = shadow.closest(vx.P, wo);
-        // Q5: visible iff the CLOSEST hit carries the light's material (pathTracing.cpp:54-58)
-        if (h.tri < 0 || s->tri_mat[h.tri] != L.mat) return false;
+        if (fixed_nee) {  // visible iff nothing lies in [0.0005, 0.999 |x' - x|)
+            if (shadow.occluded(vx.P, wo, 0.999f * length(diff))) return false;
+        } else {
+            const Hit h = shadow.closest(vx.P, wo);
+            // Q5: visible iff the CLOSEST hit carries the light's material (pathTracing.cpp:54-58)
+            if (h.tri < 0 || s->tri_mat[h.tri] != L.mat) return false;
+        }
         const float pdf_light = 1.0f / L.area;
         const float cos_theta_p = fabsf(dot(wo, light_n));
         const float cos_theta = fabsf(cos_s / length(vx.pn));
@@ -514,6 +553,7 @@ int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, o
     {
         Counters cnt;
         PathTracer pt(sv, cnt);
+        pt.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) != 0;
 #pragma omp for schedule(dynamic, 1)
         for (long r = 0; r < (long)rows.size(); ++r) {
             const int i = rows[(size_t)r];
@@ -776,6 +816,7 @@ int oracle_debug_path(const trt_scene* scene, const trt_params* p, int x, int y,
     const SceneView sv(scene);
     Counters cnt;
     PathTracer pt(sv, cnt);
+    pt.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) != 0;
     const uint32_t pixel = (uint32_t)y * (uint32_t)p->width + (uint32_t)x;
     Stream rng{trt_rng_make_key(p->seed, pixel, (uint32_t)sample), 0};
     const float u1 = rng.next(), u2 = rng.next();

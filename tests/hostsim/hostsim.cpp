@@ -96,6 +96,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
     td.rows = rows.data();
     td.tile_w = (int32_t)tw; td.x0 = p->x0; td.width = p->width; td.height = p->height;
     td.npix = npix; td.seed = p->seed; td.spp = (uint32_t)p->spp;
+    td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
     uint64_t r_cam = 0, r_sh = 0, r_ind = 0;
     const uint32_t S = (uint32_t)p->spp;  // one chunk: path id = s * npix + pixel
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : r_cam, r_sh, r_ind)
@@ -127,12 +128,14 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
                 if (cx.add_L) L = L + cx.addL;
                 for (uint32_t li = 0; li < hs.sc.n_lights; ++li) {
                     f3 wo, contrib;
-                    if (!cx.shade_ok || !lightSample(hs.sc, cx.vx, *cx.m, li, cx.rng, wo, contrib)) continue;
+                    const bool fixed = td.fixed_nee != 0u;
+                    float t_max = TRT_INF;
+                    if (!cx.shade_ok || !lightSample(hs.sc, cx.vx, *cx.m, li, cx.rng, wo, contrib, fixed, t_max)) continue;
                     const f3 w = cx.beta * contrib;
                     r_sh++;
                     // k_trace_shadow
-                    const Hit sh = traceClosest<ArrayStack, false>(hs.sc, cx.vx.P, wo, stk, ni, nt);
-                    if (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)hs.sc.lights[li].mat) L = L + w;
+                    const Hit sh = traceClosest<ArrayStack, false>(hs.sc, cx.vx.P, wo, stk, ni, nt, t_max, fixed);
+                    if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)hs.sc.lights[li].mat)) L = L + w;
                 }
                 f4 nra, nrb, nbt;
                 if (!shadeNext(cx, p->max_depth, nra, nrb, nbt)) break;

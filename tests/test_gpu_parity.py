@@ -394,3 +394,28 @@ def test_cli_progressive_render_resumes_from_its_checkpoint(tmp_path):
     img, _ = T.Renderer(s, 0).render(T.make_params(96, 54, 16, 77))
     T.imshow(img, str(tmp_path / "c.png"))
     assert open(str(tmp_path / "c.png"), "rb").read() == open(a, "rb").read()
+
+
+# ------------------------------------------------------------------ TRT_FLAG_FIXED_NEE (opt-out of Q3-Q5)
+@pytest.mark.parametrize("name,w,h,spp", [("back", 96, 54, 16), ("veach-mis", 96, 54, 8), ("staircase", 64, 36, 8)])
+def test_fixed_nee_image_matches_oracle(name, w, h, spp, renderer_factory):
+    s = get_scene(name, w, h)
+    p = T.make_params(w, h, spp, 0xF1DE, flags=T.TRT_FLAG_FIXED_NEE)
+    img, st = renderer_factory(s).render(p)
+    ref, ost = O.render(s.flat, p)
+    assert (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
+    assert np.array_equal(img, ref)
+
+
+@pytest.mark.parametrize("impl", ["1", "2", "3"])
+def test_fixed_nee_on_every_wave_driver(impl, monkeypatch):
+    """The occlusion test (stop at the first hit in front of the light sample) in the static, while-while and
+    scheduler drivers; 160 x 90 x 32 spp keeps the regular kernels (not only k_tail) busy."""
+    monkeypatch.setenv("TRT_TRACE_IMPL", impl)
+    s = get_scene("veach-mis", 160, 90)
+    r = T.Renderer(s, 0)
+    p = T.make_params(160, 90, 32, 31, flags=T.TRT_FLAG_FIXED_NEE)
+    img, st = r.render(p)
+    r.close()
+    ref, ost = O.render(s.flat, p)
+    assert np.array_equal(img, ref) and st.rays == ost.rays

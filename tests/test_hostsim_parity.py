@@ -79,6 +79,18 @@ def test_foreign_bvh_with_boxes_that_do_not_nest():
     assert (tri0 != tri2).sum() > 50
 
 
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_fixed_nee_mode_device_code_equals_oracle(name):
+    """TRT_FLAG_FIXED_NEE: own-area CDF draw, uniform light points, occlusion test (trt_path.h) == the oracle's."""
+    s = get_scene(name, 64, 36)
+    p = T.make_params(64, 36, 8, 123, flags=T.TRT_FLAG_FIXED_NEE)
+    a, sa = O.render(s.flat, p)
+    b, rays = H.render(s.flat, p)
+    assert np.array_equal(a, b) and rays == [sa.rays_camera, sa.rays_shadow, sa.rays_indirect]
+    q, _ = O.render(s.flat, T.make_params(64, 36, 8, 123))
+    assert not np.array_equal(a, q)
+
+
 def test_device_code_on_synthetic_soup_and_tiles():
     s = T.Scene.named("soup", 48, 27, n=20000)
     p = T.make_params(48, 27, 4, T.SEED_SOUP)

@@ -325,6 +325,56 @@ def test_direct_light_known_answer(tmp_path):
     assert st.rays_indirect == 0 and st.rays_shadow == st.rays_camera
 
 
+MTL_TWO_LAMPS = SU.MTL_BASIC + """newmtl lampB
+Kd 0 0 0
+Ks 0 0 0
+Ns 1
+Ni 1
+"""
+
+
+def _two_lamp_scene(tmp_path, blocker=False):
+    """Floor y = 0; lamp (first light) 0.2 x 0.2 at y = 2 over the origin; lampB 2 x 2 at y = 2 centred on x = 3.
+    `blocker`: a 1 x 1 white quad at y = 1 between the origin and the small lamp."""
+    v = ["-50 0 -50", "50 0 -50", "50 0 50", "-50 0 50", "-0.1 2 -0.1", "0.1 2 -0.1", "0.1 2 0.1", "-0.1 2 0.1", "2 2 -1", "4 2 -1", "4 2 1", "2 2 1"]
+    obj = "vt 0 0\nvn 0 1 0\nvn 0 -1 0\n" + "".join(f"v {x}\n" for x in v)
+    obj += "usemtl white\nf 1/1/1 3/1/1 2/1/1\nf 1/1/1 4/1/1 3/1/1\nusemtl lamp\nf 5/1/2 6/1/2 7/1/2\nf 5/1/2 7/1/2 8/1/2\n"
+    obj += "usemtl lampB\nf 9/1/2 10/1/2 11/1/2\nf 9/1/2 11/1/2 12/1/2\n"
+    if blocker:
+        obj += "v -0.5 1 -0.5\nv 0.5 1 -0.5\nv 0.5 1 0.5\nv -0.5 1 0.5\nusemtl white\nf 13/1/2 14/1/2 15/1/2\nf 13/1/2 15/1/2 16/1/2\n"
+    SU.write_scene(tmp_path, "two", obj, MTL_TWO_LAMPS, lights=[("lamp", (100, 100, 100)), ("lampB", (10, 10, 10))], w=16, h=16, fovy=0.5, eye=(-3, 1, 0), lookat=(0, 0, 0))
+    return SU.load(tmp_path, "two")
+
+
+def test_fixed_nee_is_unbiased_where_the_quirks_are_not(tmp_path):
+    """TRT_FLAG_FIXED_NEE (opt-out of Q3-Q5): with two lights of very different area the direct light at a floor
+    point equals the area integral of radiance * cos * cos_l / d^2 * Kd/pi; parity mode draws every light's CDF
+    with the first light's area (Q3) and is far off on the second one."""
+    s = _two_lamp_scene(tmp_path)
+    small = 100 * 0.04 / 4.0 * 0.7 / np.pi
+    xs = (np.arange(400) + 0.5) / 400 * 2 + 2
+    zs = (np.arange(400) + 0.5) / 400 * 2 - 1
+    X, Z = np.meshgrid(xs, zs)
+    big = 10 * (4.0 / (X * X + 4.0 + Z * Z) ** 2).mean() * 4.0 * 0.7 / np.pi
+    p = T.make_params(16, 16, 1024, 5, tile=(7, 7, 9, 9), max_depth=1, flags=T.TRT_FLAG_FIXED_NEE)
+    img, st = O.render(s.flat, p)
+    assert np.allclose(img.mean(axis=(0, 1)), small + big, rtol=0.03)
+    assert st.rays_shadow == 2 * st.rays_camera
+    quirk, _ = O.render(s.flat, T.make_params(16, 16, 1024, 5, tile=(7, 7, 9, 9), max_depth=1))
+    assert abs(quirk.mean() / (small + big) - 1) > 0.15
+
+
+def test_fixed_nee_shadow_test_is_an_occlusion_test(tmp_path):
+    """A quad between the floor point and the small lamp: the occlusion test removes exactly that lamp's light."""
+    s = _two_lamp_scene(tmp_path, blocker=True)
+    xs = (np.arange(400) + 0.5) / 400 * 2 + 2
+    zs = (np.arange(400) + 0.5) / 400 * 2 - 1
+    X, Z = np.meshgrid(xs, zs)
+    big = 10 * (4.0 / (X * X + 4.0 + Z * Z) ** 2).mean() * 4.0 * 0.7 / np.pi
+    img, _ = O.render(s.flat, T.make_params(16, 16, 1024, 5, tile=(7, 7, 9, 9), max_depth=1, flags=T.TRT_FLAG_FIXED_NEE))
+    assert np.allclose(img.mean(axis=(0, 1)), big, rtol=0.03)
+
+
 def test_image_statistics_against_reference_snapshots():
     """Loose pin: mean linear RGB of the reference's own 10-spp renders of test/back
     (image10.png 0.220/0.218/0.071, image10-0.png 0.237/0.243/0.098, 6.9 % black pixels), measured the

@@ -15,6 +15,7 @@ TRT_INF = 114514.0
 TRT_FLAG_TIMING = 1
 TRT_FLAG_COUNT = 2
 TRT_FLAG_OVERLAP = 4
+TRT_FLAG_FIXED_NEE = 8
 TRT_MAX_KERNELS = 8
 KERNEL_NAMES = ["gen_primary", "trace_closest", "shade", "trace_shadow", "resolve", "tail"]
 

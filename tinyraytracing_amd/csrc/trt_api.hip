@@ -172,7 +172,7 @@ uint32_t traceGrid(uint32_t n)
 template <bool COUNT, bool PRIMARY>
 void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats);
 template <bool COUNT>
-void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats);
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any);
 
 struct Timer {
     trt_handle* h;
@@ -232,24 +232,24 @@ void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill
 }
 
 template <bool COUNT>
-void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats)
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any)
 {
     const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_shadow<COUNT, 1, false, 0>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+    if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_shadow<COUNT, 1, false, 0>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
     else if (h->trace_impl == 1) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
+        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
     }
     else if (h->trace_impl == 2) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
+        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
     }
     else if (h->trace_impl == 3) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats);
+        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
+        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
+        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
     }
 }
 
@@ -514,8 +514,11 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     td.npix = npix;
     td.seed = p->seed;
     td.spp = (uint32_t)p->spp;
+    td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
 
-    Timer tm{h, (p->flags & TRT_FLAG_TIMING) != 0};
+    Timer tm;
+    tm.h = h;
+    tm.on = (p->flags & TRT_FLAG_TIMING) != 0;
     trt_stats st;
     std::memset(&st, 0, sizeof(st));
     // events 0/1 bracket the render on the caller's stream, 2 chains the ordered resolves
@@ -593,8 +596,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
             if (ns > S.n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");
             if (!ns) continue;
             tm.begin(TRT_K_TRACE_SHADOW, S.stream);
-            if (count) launchTraceShadow<true>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats);
-            else launchTraceShadow<false>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats);
+            if (count) launchTraceShadow<true>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee);
+            else launchTraceShadow<false>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee);
             tm.end(S.stream);
             st.launches[TRT_K_TRACE_SHADOW]++;
             st.rays_shadow += ns;

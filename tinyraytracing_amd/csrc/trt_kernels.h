@@ -163,7 +163,7 @@ struct TraceProbe {  // COUNT builds only: work and SIMD utilisation of the two 
 // result of one ray: hit record (closest) or the NEE accumulation (shadow)
 template <bool SHADOW>
 __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, float best_t, int32_t best_tri, uint32_t best_flags, uint32_t idx, uint32_t pid,
-                                            f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc)
+                                            f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, bool any)
 {
     if (!SHADOW) {
         // barycentric weights of v1, v2 (what findBaryCor feeds bvh.cpp:224): re-evaluated on the winning
@@ -174,8 +174,9 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
             if (triTest(sc.tri_isect[best_tri], o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
         }
         hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
-    } else if (best_tri >= 0 && (best_flags >> 8) == light_mat) {
-        // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material
+    } else if (any ? best_tri < 0 : (best_tri >= 0 && (best_flags >> 8) == light_mat)) {
+        // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material;
+        // TRT_FLAG_FIXED_NEE (`any`): visible iff nothing lies in front of the light sample
         const f4 w = sw[idx];
         f4 L = Lacc[pid];
         L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
@@ -193,8 +194,9 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
 // the leaf rule and the between-leaves rule are applied unchanged.
 template <bool SHADOW, bool COUNT, bool PRIMARY>
 __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
-                                                  const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, DeviceStats* stats)
+                                                  const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, DeviceStats* stats, bool any_flag)
 {
+    const bool any = SHADOW && any_flag;  // occlusion test (TRT_FLAG_FIXED_NEE): the ray carries its own t_max in rb.w
     uint32_t n_inner = 0, n_tri = 0;
     const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
     const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
@@ -208,7 +210,7 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
         const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         uint32_t reach = valid ? 1u : 0u;  // bit k: the ray reaches inner node k
-        float best_t = TRT_INF;
+        float best_t = any ? b.w : TRT_INF;
         int32_t best_tri = -1;
         uint32_t best_flags = 0u;
         for (uint32_t ni = 0; ni < n_nodes; ++ni) {
@@ -250,10 +252,11 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
                         take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
                     }
                     if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
+                    if (any && best_tri >= 0) reach = 0u;  // occluded: this lane is done with the tree
                 }
             }
         }
-        if (valid) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc);
+        if (valid) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
     }
     if (COUNT) {
         const unsigned long long si = waveSum(n_inner), st = waveSum(n_tri);
@@ -267,7 +270,7 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
 __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
 {
     LdsStack<DEPTH, SPILL> stk;
     stk.lds = smem + threadIdx.x;
@@ -279,10 +282,11 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySo
     for (uint32_t i = lb * TRT_TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
         f4 a, b;
         fetchRay<PRIMARY>(sc, src, i, a, b);
-        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri);
+        const bool any = SHADOW && any_flag;
+        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri, any ? b.w : TRT_INF, any);
         if (!SHADOW) {
             hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
-        } else if (h.tri >= 0 && (h.flags >> 8) == light_mat) {
+        } else if (any ? h.tri < 0 : (h.tri >= 0 && (h.flags >> 8) == light_mat)) {
             const f4 w = sw[i];
             const uint32_t pid = f2u(b.z);
             f4 L = Lacc[pid];
@@ -301,12 +305,13 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySo
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
 __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
 {
     LdsStack<DEPTH, SPILL> stk;
     stk.lds = smem + threadIdx.x;
     stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
     stk.spill_stride = spill_stride;
+    const bool any = SHADOW && any_flag;  // occlusion test (TRT_FLAG_FIXED_NEE): the ray carries its own t_max in rb.w
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lower = (1ull << lane) - 1ull;
     // contiguous queue slice of this wave (XCD-aware: neighbouring slices share an L2)
@@ -339,7 +344,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         const bool can_fill = next < end;
         if (m_work == 0ull || (m_done != 0ull && __popcll(can_fill ? m_free : m_done) >= TRT_REFILL_MIN)) {
             if (cur == TRT_REF_DONE) {
-                storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc);
+                storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc, any);
                 cur = TRT_REF_IDLE;
             }
             if (can_fill) {
@@ -352,7 +357,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                     d = mk3(a.w, b.x, b.y);
                     if (SHADOW) pid = f2u(b.z);
                     inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    best_t = TRT_INF; best_tri = -1; best_flags = 0u;
+                    best_t = any ? b.w : TRT_INF; best_tri = -1; best_flags = 0u;
                     sp = 0;
                     cur = 0u;  // nodes[0] is always an inner node
                     lk = 0; lt = TRT_INF; li = -1;
@@ -405,7 +410,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                     }
                     if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
                 }
-                if (sp == 0) cur = TRT_REF_DONE;
+                if (sp == 0 || (any && best_tri >= 0)) cur = TRT_REF_DONE;
                 else cur = stk.pop(--sp);
             }
             if (COUNT && lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_tri++;
@@ -451,7 +456,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             }
         }
         if (adv) {
-            if (sp == 0) cur = TRT_REF_DONE;
+            if (sp == 0 || (any && best_tri >= 0)) cur = TRT_REF_DONE;
             else cur = stk.pop(--sp);
             lk = 0; lt = TRT_INF; li = -1;
         }
@@ -471,11 +476,11 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
 __device__ __forceinline__ void traceQueue(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem)
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
 {
-    if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats);
-    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
-    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+    if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats, any_flag);
+    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
+    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
 }
 
 // PRIMARY: bounce 0 — ray i is the camera ray of path i, generated in registers (K1 of SURVEY.md §7 fused
@@ -485,7 +490,7 @@ __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4*
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
     __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
-    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem);
+    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false);
 }
 
 // Shadow test of shade() (pathTracing.cpp:51-58): CLOSEST hit, visible iff
@@ -494,14 +499,14 @@ __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4*
 // write of Lacc needs no atomic and the sum order is fixed.
 template <bool COUNT, int DEPTH, bool SPILL, int IMPL>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
-                                                uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
+                                                uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any)
 {
     __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;
     src.s0 = 0;
-    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem);
+    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u);
 }
 
 // Block-wide stream compaction in two halves.  blockStage: every thread calls it with its `flag`; wave
@@ -619,20 +624,22 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         bool pend_emit = false;
         uint32_t pend_rank = 0, pend_li = 0;
         f3 pend_wo = mk3(0, 0, 0), pend_w = mk3(0, 0, 0);
+        float pend_tmax = TRT_INF;  // TRT_FLAG_FIXED_NEE: how far the occlusion test of the shadow ray reaches
         for (uint32_t li = 0; li < sc.n_lights; ++li) {
             bool emit = false;
             f3 wo = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
-            if (c.shade_ok) emit = lightSample(sc, c.vx, *c.m, li, c.rng, wo, contrib);
+            float t_max = TRT_INF;
+            if (c.shade_ok) emit = lightSample(sc, c.vx, *c.m, li, c.rng, wo, contrib, A.td.fixed_nee != 0u, t_max);
             uint32_t rank;
             uint32_t* s = blockStage<TRT_SHADE_BLOCK>(emit, A.shadow_counts + (size_t)li * A.shadow_count_stride, s_cnt, parity, rank, pend_s, pend_base);
             parity = parity == 2 ? 0 : parity + 1;
             if (pend_emit) {
                 const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
                 A.sq[pend_li].sa[slot] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, pend_wo.x);  // Q6: origin = hit point, no offset
-                A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), 0.0f);
+                A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
                 A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
             }
-            pend_s = s; pend_emit = emit; pend_rank = rank; pend_li = li; pend_wo = wo; pend_w = c.beta * contrib;
+            pend_s = s; pend_emit = emit; pend_rank = rank; pend_li = li; pend_wo = wo; pend_w = c.beta * contrib; pend_tmax = t_max;
         }
         f4 nra, nrb, nbt;
         const bool emit_next = shadeNext(c, A.max_depth, nra, nrb, nbt);
@@ -642,7 +649,7 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         if (pend_emit) {
             const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
             A.sq[pend_li].sa[slot] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, pend_wo.x);
-            A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), 0.0f);
+            A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
             A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
         }
         if (threadIdx.x == 0) s_next[TRT_SHADE_BLOCK / 64] = pend_base;  // publish the last base
@@ -706,11 +713,13 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
             if (c.shade_ok) n_shaded++;
             for (uint32_t li = 0; li < sc.n_lights; ++li) {
                 f3 wo, contrib;
-                if (!c.shade_ok || !lightSample(sc, c.vx, *c.m, li, c.rng, wo, contrib)) continue;
+                const bool fixed = A.td.fixed_nee != 0u;
+                float t_max = TRT_INF;
+                if (!c.shade_ok || !lightSample(sc, c.vx, *c.m, li, c.rng, wo, contrib, fixed, t_max)) continue;
                 const f3 w = c.beta * contrib;
                 n_shadow++;
-                const Hit sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1]);
-                if (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)sc.lights[li].mat) { L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z; }
+                const Hit sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1], t_max, fixed);
+                if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)sc.lights[li].mat)) { L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z; }
             }
             f4 nra, nrb, nbt;
             if (!shadeNext(c, A.max_depth, nra, nrb, nbt)) break;

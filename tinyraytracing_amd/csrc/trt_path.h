@@ -330,11 +330,13 @@ TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& 
 //                     rightmost candidate wins.
 // Stack: push(sp, ref) / pop(sp) with sp < scene depth.
 template <class Stack, bool COUNT>
-TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri)
+// `t_init` bounds the search (only hits STRICTLY nearer count) and `any` stops at the first leaf that yields
+// one: together they make the occlusion test of TRT_FLAG_FIXED_NEE (tri >= 0 <=> something lies in front of t_init).
+TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false)
 {
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     Hit best;
-    best.t = TRT_INF; best.tri = -1; best.u = 0.f; best.v = 0.f; best.flags = 0u;
+    best.t = t_init; best.tri = -1; best.u = 0.f; best.v = 0.f; best.flags = 0u;
     float best_det = 1.0f;  // best.u / best.v hold the numerators un, vn until the end
     int sp = 0;
     uint32_t cur = 0;  // nodes[0] is always an inner node
@@ -375,7 +377,7 @@ TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
                 }
                 if (take) { best.t = lt; best.tri = li; best.u = lun; best.v = lvn; best_det = ldet; best.flags = lflags; }
             }
-            if (sp == 0) break;
+            if (sp == 0 || (any && best.tri >= 0)) break;
             cur = stk.pop(--sp);
             continue;
         }
@@ -513,10 +515,13 @@ TRT_HD inline Vertex makeVertex(const SceneDev& sc, const Hit& h, f3 o, f3 d, co
 // shadow ray (pathTracing.cpp:34-53).  Returns true when a shadow ray must be
 // traced; `wo` is its direction, `contrib` what it adds to L_dir if the closest
 // hit carries the light's material (pathTracing.cpp:55-70).
-TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const MaterialDev& m, uint32_t li, Stream& rng, f3& wo, f3& contrib)
+// `fixed` (TRT_FLAG_FIXED_NEE): the CDF draw spans this light's own area (not Q3), the point is uniform on the
+// triangle (not Q4), and `t_max` = 0.999 |x' - x| bounds the occlusion test that replaces the closest-hit +
+// material comparison (not Q5); t_max is TRT_INF in parity mode.
+TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const MaterialDev& m, uint32_t li, Stream& rng, f3& wo, f3& contrib, bool fixed, float& t_max)
 {
     const LightDev L = sc.lights[li];
-    const float rnd = rng.next() * sc.light0_area;  // Q3
+    const float rnd = rng.next() * (fixed ? L.area : sc.light0_area);  // Q3
     // first triangle whose cumulative area exceeds rnd (the linear scan of pathTracing.cpp:38-42); on a
     // non-decreasing CDF a bisection finds the same index
     uint32_t pick = L.tri_count;
@@ -535,14 +540,21 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
     const LightTriDev T = sc.light_tris[L.tri_first + pick];  // whole record: five 16-B loads
     const LightTriDev* lt = &T;
     const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
-    const float rs = (r1 + r2) + r3;
-    const float p1 = r1 / rs, p2 = r2 / rs, p3 = r3 / rs;  // Q4
+    float p1, p2, p3;
+    if (fixed) {  // uniform on the triangle; r3 is drawn (same stream layout) but unused
+        const float su = sqrtf(r1);
+        p1 = 1.0f - su; p2 = su * (1.0f - r2); p3 = su * r2;
+    } else {
+        const float rs = (r1 + r2) + r3;
+        p1 = r1 / rs; p2 = r2 / rs; p3 = r3 / rs;  // Q4
+    }
     const f3 light_p = (ld3(lt->v[0]) * p1 + ld3(lt->v[1]) * p2) + ld3(lt->v[2]) * p3;
     const f3 light_n = normalize((ld3(lt->vn[0]) * p1 + ld3(lt->vn[1]) * p2) + ld3(lt->vn[2]) * p3);
     const f3 diff = light_p - vx.P;
     wo = normalize(diff);
     const float cos_s = dot(wo, vx.pn);
     if (!(cos_s > 0.0f)) return false;  // pathTracing.cpp:60: such a sample never contributes
+    t_max = fixed ? 0.999f * length(diff) : TRT_INF;
     const float pdf_light = L.pdf;  // 1 / area, makeLightDev
     const float cos_theta_p = fabsf(dot(wo, light_n));
     const float cos_theta = fabsf(cos_s / length(vx.pn));
@@ -573,6 +585,7 @@ TRT_HD inline uint32_t metaDepth(uint32_t m) { return m >> 20; }
 struct TileDesc {
     const int32_t* rows;  // image row of each packed output row
     int32_t tile_w, x0, width, height;
+    uint32_t fixed_nee;   // TRT_FLAG_FIXED_NEE
     uint32_t npix;        // rows * tile_w
     uint32_t seed, spp;
 };
