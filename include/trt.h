@@ -141,6 +141,8 @@ typedef struct trt_scene {
                               * draw spans that light's own area, light points are uniform on the chosen triangle, and the
                               * shadow test is an occlusion test up to the light sample (any hit in [0.0005, 0.999 * distance)
                               * blocks; a miss is visible) instead of closest-hit + material comparison.  Off = parity mode. */
+#define TRT_FLAG_FIXED_PIXELS 16u /* opt out of the pixel-grid quirks (Q1, Q2): pixel (i, j) samples its own cell
+                                  * [j/W, (j+1)/W) x [(H-1-i)/H, (H-i)/H) of the image plane uniformly.  Off = parity mode. */
 
 typedef struct trt_params {
     int32_t width, height;   /* full image size (scene.img_width/height, scene.cpp:13-14) */

@@ -505,12 +505,18 @@ struct PathTracer {
 };
 
 // main.cpp:88-95 + camera.cpp:19-28
-inline void cameraRay(const trt_camera& cam, int W, int H, int i, int j, float u1, float u2, V3& o, V3& d)
+inline void cameraRay(const trt_camera& cam, int W, int H, int i, int j, float u1, float u2, V3& o, V3& d, bool fixed = false)
 {
-    double x = double(j) / double(W - 1.0);
-    double y = double(H - i) / double(H - 1.0);  // Q1: H - i
-    x += ((double)u1 - 0.5) / double(W);         // Q2
-    y += ((double)u2 - 0.5) / double(H);
+    double x, y;
+    if (fixed) {  // TRT_FLAG_FIXED_PIXELS: uniform inside the pixel's own cell of a W x H grid
+        x = (double(j) + (double)u1) / double(W);
+        y = (double(H - 1 - i) + (double)u2) / double(H);
+    } else {
+        x = double(j) / double(W - 1.0);
+        y = double(H - i) / double(H - 1.0);  // Q1: H - i
+        x += ((double)u1 - 0.5) / double(W);  // Q2
+        y += ((double)u2 - 0.5) / double(H);
+    }
     const float s = (float)x, t = (float)y;
     const V3 llc = ld(cam.lower_left_corner), hor = ld(cam.horizontal), ver = ld(cam.vertical), eye = ld(cam.eye);
     o = eye;
@@ -564,7 +570,7 @@ int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, o
                     Stream rng{trt_rng_make_key(p->seed, pixel, (uint32_t)k), 0};
                     const float u1 = rng.next(), u2 = rng.next();
                     V3 o, d;
-                    cameraRay(scene->camera, p->width, p->height, i, j, u1, u2, o, d);
+                    cameraRay(scene->camera, p->width, p->height, i, j, u1, u2, o, d, (p->flags & TRT_FLAG_FIXED_PIXELS) != 0);
                     const V3 L = (mode == ORACLE_MODE_RECURSIVE) ? pt.pathRecursive(o, d, rng) : pt.pathIterative(o, d, rng, p->max_depth);
                     const V3 color = L / (float)p->spp;  // main.cpp:101
                     acc[0] += color.x;
@@ -788,6 +794,13 @@ void oracle_refract(const float I[3], const float N[3], float eta, float out[3])
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+void oracle_camera_ray_mode(const trt_camera* cam, int width, int height, int i, int j, float u1, float u2, int fixed, float org[3], float dir[3])
+{
+    V3 o, d;
+    cameraRay(*cam, width, height, i, j, u1, u2, o, d, fixed != 0);
+    org[0] = o.x; org[1] = o.y; org[2] = o.z;
+    dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+}
 void oracle_camera_ray(const trt_camera* cam, int width, int height, int i, int j, float u1, float u2, float org[3], float dir[3])
 {
     V3 o, d;
@@ -821,7 +834,7 @@ int oracle_debug_path(const trt_scene* scene, const trt_params* p, int x, int y,
     Stream rng{trt_rng_make_key(p->seed, pixel, (uint32_t)sample), 0};
     const float u1 = rng.next(), u2 = rng.next();
     V3 o, d;
-    cameraRay(scene->camera, p->width, p->height, y, x, u1, u2, o, d);
+    cameraRay(scene->camera, p->width, p->height, y, x, u1, u2, o, d, (p->flags & TRT_FLAG_FIXED_PIXELS) != 0);
     int n = 0;
     pt.pathIterative(o, d, rng, p->max_depth, out, max_vertices, &n);
     return n;

@@ -55,6 +55,9 @@ void oracle_refract(const float I[3], const float N[3], float eta, float out[3])
 /* main.cpp:88-95 + camera.cpp:19-28 for pixel row i, column j with jitter draws u1,u2. */
 void oracle_camera_ray(const trt_camera* cam, int width, int height, int i, int j, float u1, float u2,
                        float org[3], float dir[3]);
+/* the same with TRT_FLAG_FIXED_PIXELS' mapping when fixed != 0 */
+void oracle_camera_ray_mode(const trt_camera* cam, int width, int height, int i, int j, float u1, float u2, int fixed,
+                            float org[3], float dir[3]);
 /* nextRay (pathTracing.cpp:147-209) on explicit inputs; draws come from (seed,pixel,sample) at
  * counter *ctr (advanced).  Returns the ray type; out_dir is the new direction. */
 int oracle_next_ray(const trt_material* m, const float pn[3], const float incoming[3], uint32_t seed,

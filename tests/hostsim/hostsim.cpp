@@ -97,6 +97,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
     td.tile_w = (int32_t)tw; td.x0 = p->x0; td.width = p->width; td.height = p->height;
     td.npix = npix; td.seed = p->seed; td.spp = (uint32_t)p->spp;
     td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
+    td.fixed_pixels = (p->flags & TRT_FLAG_FIXED_PIXELS) ? 1u : 0u;
     uint64_t r_cam = 0, r_sh = 0, r_ind = 0;
     const uint32_t S = (uint32_t)p->spp;  // one chunk: path id = s * npix + pixel
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : r_cam, r_sh, r_ind)
@@ -114,7 +115,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
             rng.ctr = 0;
             const float u1 = rng.next(), u2 = rng.next();
             f3 o, d;
-            cameraRay(hs.sc.cam, td.width, td.height, y, x, u1, u2, o, d);
+            cameraRay(hs.sc.cam, td.width, td.height, y, x, u1, u2, o, d, td.fixed_pixels != 0u);
             f4 ra = mk4(o.x, o.y, o.z, d.x), rb = mk4(d.y, d.z, u2f(pid), u2f(packMeta(rng.ctr, TRT_META_CAMERA, 0))), bt = mk4(1, 1, 1, 0);
             f3 L = mk3(0, 0, 0);
             r_cam++;

@@ -46,6 +46,7 @@ def lib():
     L.oracle_reflect.argtypes = [fp, fp, fp]
     L.oracle_refract.argtypes = [fp, fp, C.c_float, fp]
     L.oracle_camera_ray.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]
+    L.oracle_camera_ray_mode.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, fp, fp]
     L.oracle_next_ray.argtypes = [C.POINTER(Material), fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), fp]
     L.oracle_prims_sincos2pi.argtypes = [C.c_float, fp, fp]
     L.oracle_prims_pow01.restype = C.c_float
@@ -135,10 +136,13 @@ def refract(I, N, eta):
     return out
 
 
-def camera_ray(cam, width, height, i, j, u1, u2):
+def camera_ray(cam, width, height, i, j, u1, u2, fixed=False):
     o = np.zeros(3, np.float32)
     d = np.zeros(3, np.float32)
-    lib().oracle_camera_ray(C.byref(cam), width, height, i, j, u1, u2, o.ctypes.data_as(fp), d.ctypes.data_as(fp))
+    if fixed:
+        lib().oracle_camera_ray_mode(C.byref(cam), width, height, i, j, u1, u2, 1, o.ctypes.data_as(fp), d.ctypes.data_as(fp))
+    else:
+        lib().oracle_camera_ray(C.byref(cam), width, height, i, j, u1, u2, o.ctypes.data_as(fp), d.ctypes.data_as(fp))
     return o, d
 
 

@@ -419,3 +419,16 @@ def test_fixed_nee_on_every_wave_driver(impl, monkeypatch):
     r.close()
     ref, ost = O.render(s.flat, p)
     assert np.array_equal(img, ref) and st.rays == ost.rays
+
+
+def test_fixed_pixels_and_nee_together_match_oracle(renderer_factory):
+    """TRT_FLAG_FIXED_PIXELS | TRT_FLAG_FIXED_NEE: the 'fixed' renderer a user would pick — same bar as parity mode."""
+    s = get_scene("staircase", 80, 45)
+    p = T.make_params(80, 45, 8, 4242, flags=T.TRT_FLAG_FIXED_PIXELS | T.TRT_FLAG_FIXED_NEE)
+    img, st = renderer_factory(s).render(p)
+    ref, ost = O.render(s.flat, p)
+    assert np.array_equal(img, ref) and st.rays == ost.rays
+    only_px = T.make_params(80, 45, 8, 4242, flags=T.TRT_FLAG_FIXED_PIXELS)
+    a, _ = renderer_factory(s).render(only_px)
+    b, _ = O.render(s.flat, only_px)
+    assert np.array_equal(a, b) and not np.array_equal(a, img)

@@ -91,6 +91,27 @@ def test_fixed_nee_mode_device_code_equals_oracle(name):
     assert not np.array_equal(a, q)
 
 
+def test_fixed_pixels_mode_device_code_equals_oracle_and_centres_the_image():
+    """TRT_FLAG_FIXED_PIXELS (opt-out of Q1/Q2): same bits as the oracle; and the image is no longer shifted by a row:
+    a scene that is mirror-symmetric top/bottom about the optical axis renders symmetric hit masks."""
+    s = get_scene("back", 64, 64)
+    fl = T.TRT_FLAG_FIXED_PIXELS | T.TRT_FLAG_FIXED_NEE
+    p = T.make_params(64, 64, 8, 9, flags=fl)
+    a, sa = O.render(s.flat, p)
+    b, rays = H.render(s.flat, p)
+    assert np.array_equal(a, b) and rays == [sa.rays_camera, sa.rays_shadow, sa.rays_indirect]
+    # the quirk grid samples t = (H - i)/(H - 1) > 1 in the top row (above the image plane): with the fixed grid
+    # every sample lies inside [0,1)^2, so the camera ray of pixel (i, j) and of (H-1-i, j) mirror each other
+    cam = s.flat.contents.camera
+    o0, d0 = O.camera_ray(cam, 64, 64, 0, 10, 0.5, 0.5, fixed=True)
+    o1, d1 = O.camera_ray(cam, 64, 64, 63, 10, 0.5, 0.5, fixed=True)
+    up = np.array(cam.vertical[:], np.float64); up /= np.linalg.norm(up)
+    assert abs(np.dot(d0, up) + np.dot(d1, up)) < 1e-6
+    q0, e0 = O.camera_ray(cam, 64, 64, 0, 10, 0.5, 0.5)
+    q1, e1 = O.camera_ray(cam, 64, 64, 63, 10, 0.5, 0.5)
+    assert abs(np.dot(e0, up) + np.dot(e1, up)) > 1e-3
+
+
 def test_device_code_on_synthetic_soup_and_tiles():
     s = T.Scene.named("soup", 48, 27, n=20000)
     p = T.make_params(48, 27, 4, T.SEED_SOUP)

@@ -402,12 +402,20 @@ struct Stream {
 };
 
 // ------------------------------------- primary ray (main.cpp:88-95, a1/a2) ----
-TRT_HD inline void cameraRay(const trt_camera& cam, int W, int H, int i, int j, float u1, float u2, f3& o, f3& d)
+// `fixed` (TRT_FLAG_FIXED_PIXELS): pixel (i, j) covers [j/W, (j+1)/W) x [(H-1-i)/H, (H-i)/H) of the image plane and the
+// jitter is uniform inside it, instead of Q1 (rows shifted by one, pitch 1/(H-1)) and Q2 (jitter of 1/W on a 1/(W-1) grid).
+TRT_HD inline void cameraRay(const trt_camera& cam, int W, int H, int i, int j, float u1, float u2, f3& o, f3& d, bool fixed = false)
 {
-    double x = double(j) / double(W - 1.0);
-    double y = double(H - i) / double(H - 1.0);  // Q1
-    x += ((double)u1 - 0.5) / double(W);         // Q2
-    y += ((double)u2 - 0.5) / double(H);
+    double x, y;
+    if (fixed) {
+        x = (double(j) + (double)u1) / double(W);
+        y = (double(H - 1 - i) + (double)u2) / double(H);
+    } else {
+        x = double(j) / double(W - 1.0);
+        y = double(H - i) / double(H - 1.0);  // Q1
+        x += ((double)u1 - 0.5) / double(W);  // Q2
+        y += ((double)u2 - 0.5) / double(H);
+    }
     const float s = (float)x, t = (float)y;
     const f3 llc = ld3(cam.lower_left_corner), hor = ld3(cam.horizontal), ver = ld3(cam.vertical), eye = ld3(cam.eye);
     o = eye;
@@ -586,6 +594,7 @@ struct TileDesc {
     const int32_t* rows;  // image row of each packed output row
     int32_t tile_w, x0, width, height;
     uint32_t fixed_nee;   // TRT_FLAG_FIXED_NEE
+    uint32_t fixed_pixels;  // TRT_FLAG_FIXED_PIXELS
     uint32_t npix;        // rows * tile_w
     uint32_t seed, spp;
 };
@@ -612,7 +621,7 @@ TRT_HD inline void primaryRay(const SceneDev& sc, const TileDesc& td, uint32_t s
     rng.ctr = 0;
     const float u1 = rng.next(), u2 = rng.next();  // jitter x, then y (main.cpp:92-93)
     f3 o, d;
-    cameraRay(sc.cam, td.width, td.height, y, x, u1, u2, o, d);
+    cameraRay(sc.cam, td.width, td.height, y, x, u1, u2, o, d, td.fixed_pixels != 0u);
     ra = mk4(o.x, o.y, o.z, d.x);
     rb = mk4(d.y, d.z, u2f(pid), u2f(packMeta(rng.ctr, TRT_META_CAMERA, 0)));
 }
