@@ -74,7 +74,7 @@ struct trt_handle {
     uint32_t bvh2_depth = 0;  // depth of the caller's BVH2
     uint32_t lds_tab[4] = {0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles that k_shade stages in LDS
     int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
-    uint32_t tail_n = 32768;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
+    uint32_t tail_n = 131072;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
     DevBuf arena, spill, small_buf, out_buf, io_buf;
     size_t spill_words_per_slot = 0;
     hipStream_t slot_streams[2] = {nullptr, nullptr};  // one per concurrent pass (trt_render_device)
