@@ -451,29 +451,43 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     const uint32_t npix = (uint32_t)npix64;
 
     // ---- chunking: how many samples of every pixel one pass holds; >= N_SLOTS passes when spp allows ----
+    // Passes are as large as HBM allows: every pass ends in a tail of few, long paths, so fewer and larger passes
+    // are faster (back 1080p x 256 spp: 3 passes in 32 GiB 101.4 ms, 1 pass in 93 GB 96.8 ms).  Default budget:
+    // three quarters of what is free on the device (the scene is already resident); halved on an allocation failure.
     const uint64_t bytes_per_path = 2ull * 48 + 16 + 16 + (uint64_t)nl * 48;
     uint64_t budget = p->mem_budget;
-    if (!budget) {
+    const bool own_budget = budget == 0;
+    if (own_budget) {
         size_t free_b = 0, total_b = 0;
         HIPC(hipMemGetInfo(&free_b, &total_b));
-        budget = std::min<uint64_t>((uint64_t)(free_b + h->arena.bytes) / 2, 32ull << 30);
+        budget = (uint64_t)(free_b + h->arena.bytes) / 4 * 3;
     }
     const int n_slots = (n_samples >= 2 && (p->flags & TRT_FLAG_OVERLAP) && h->n_slots > 1) ? N_SLOTS : 1;
-    uint64_t max_paths = std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull);
-    if (max_paths < npix) return fail(TRT_ENOMEM, "mem_budget too small for one sample of every pixel of the tile; render smaller tiles");
-    if (n_slots > 1 && max_paths / n_slots >= npix) max_paths /= n_slots;  // each slot gets its share of the budget
-    const int slots_used = (max_paths * n_slots <= std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull)) ? n_slots : 1;
-    uint32_t s_chunk = (uint32_t)std::min<uint64_t>((uint64_t)n_samples, max_paths / npix);
-    uint32_t n_chunks = (n_samples + s_chunk - 1) / s_chunk;
-    if (slots_used > 1 && n_chunks < (uint32_t)slots_used) n_chunks = (uint32_t)std::min<uint32_t>((uint32_t)slots_used, n_samples);
-    s_chunk = (n_samples + n_chunks - 1) / n_chunks;
-    n_chunks = (n_samples + s_chunk - 1) / s_chunk;
-    const uint64_t N = (uint64_t)npix * s_chunk;
-
-    // ---- carve the arena: one set of queues per slot -------------------------------
-    const size_t q16 = (size_t)N * sizeof(f4);
-    const size_t per_slot = q16 * (3 * 2 + 1 + 1 + 3 * (size_t)nl);
-    if (int e = h->arena.ensure(per_slot * (size_t)slots_used)) return e;
+    int slots_used = 1;
+    uint32_t s_chunk = 1, n_chunks = 1;
+    uint64_t N = 0;
+    size_t q16 = 0, per_slot = 0;
+    for (;;) {
+        const uint64_t cap_paths = std::min<uint64_t>(budget / bytes_per_path, 0x7FFF0000ull);
+        uint64_t max_paths = cap_paths;
+        if (max_paths < npix) return fail(TRT_ENOMEM, "mem_budget too small for one sample of every pixel of the tile; render smaller tiles");
+        if (n_slots > 1 && max_paths / n_slots >= npix) max_paths /= n_slots;  // each slot gets its share of the budget
+        slots_used = (max_paths * n_slots <= cap_paths) ? n_slots : 1;
+        s_chunk = (uint32_t)std::min<uint64_t>((uint64_t)n_samples, max_paths / npix);
+        n_chunks = (n_samples + s_chunk - 1) / s_chunk;
+        if (slots_used > 1 && n_chunks < (uint32_t)slots_used) n_chunks = (uint32_t)std::min<uint32_t>((uint32_t)slots_used, n_samples);
+        s_chunk = (n_samples + n_chunks - 1) / n_chunks;
+        n_chunks = (n_samples + s_chunk - 1) / s_chunk;
+        N = (uint64_t)npix * s_chunk;
+        // ---- carve the arena: one set of queues per slot
+        q16 = (size_t)N * sizeof(f4);
+        per_slot = q16 * (3 * 2 + 1 + 1 + 3 * (size_t)nl);
+        const int e = h->arena.ensure(per_slot * (size_t)slots_used);
+        if (e == TRT_OK) break;
+        if (e != TRT_ENOMEM || !own_budget || budget / 2 < bytes_per_path * npix) return e;
+        (void)hipGetLastError();  // the failed hipMalloc
+        budget /= 2;
+    }
     const size_t rows_bytes = (rows.size() * sizeof(int32_t) + 255) & ~(size_t)255;
     const size_t counts_bytes = (size_t)COUNT_STRIDE * COUNT_ROW * sizeof(uint32_t);
     const size_t stats_bytes = 256;
