@@ -159,10 +159,25 @@ int checkParams(const trt_handle* h, const trt_params* p)
 
 bool rowSelected(const trt_params* p, int y) { return p->row_mod <= 1 || ((y / p->row_block) % p->row_mod) == p->row_rem; }
 
-uint32_t traceGrid(uint32_t n)
+// Grid of the traversal kernels for a queue of n rays.  A persistent wave refills finished lanes from its own slice
+// of the queue, which only pays when the slice holds several batches: aim for g_rays_per_wave rays per wave, but do
+// not go below the g_fill_blocks that fill the chip's wave slots, nor above one block per 256 rays.
+// (TRT_TRACE_RPW / TRT_TRACE_FILLB / TRT_TRACE_MAXB in the environment: tuning.)
+uint32_t g_rays_per_wave = 256, g_fill_blocks = 2048, g_max_blocks = MAX_TRACE_BLOCKS;
+uint32_t tailGrid(uint32_t n)
 {
     uint32_t b = (n + TRT_TRACE_BLOCK - 1) / TRT_TRACE_BLOCK;
     b = std::min(std::max(b, 8u), MAX_TRACE_BLOCKS);
+    return (b + 7u) & ~7u;
+}
+uint32_t traceGrid(uint32_t n)
+{
+    uint32_t b = (n + TRT_TRACE_BLOCK - 1) / TRT_TRACE_BLOCK;
+    if (g_rays_per_wave > 64) {
+        const uint32_t want = (uint32_t)(((uint64_t)n + 4ull * g_rays_per_wave - 1) / (4ull * g_rays_per_wave));
+        b = std::min(b, std::max(g_fill_blocks, want));
+    }
+    b = std::min(std::max(b, 8u), std::min(g_max_blocks, MAX_TRACE_BLOCKS));
     return (b + 7u) & ~7u;  // multiple of 8 for the XCD swizzle; <= MAX_TRACE_BLOCKS since that is one too
 }
 
@@ -304,6 +319,9 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     h->device = device;
     h->bvh2_depth = depth;
     if (const char* e = std::getenv("TRT_TAIL_N")) h->tail_n = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TRT_TRACE_RPW")) g_rays_per_wave = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TRT_TRACE_FILLB")) g_fill_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TRT_TRACE_MAXB")) g_max_blocks = std::max(8u, (uint32_t)std::strtoul(e, nullptr, 10));
     // shallow trees (everything L1-resident, a dozen steps per ray): the static driver has the least overhead;
     // deeper ones gain more from lane refill and step scheduling (measured: DESIGN.md)
     const bool tiny = s->n_nodes <= 32 && s->n_tris <= 64;  // the wave-uniform walk needs a 32-bit reach mask
@@ -636,8 +654,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
             TA.spill_stride = SPILL_STRIDE;
             TA.stats = d_stats;
             tm.begin(TRT_K_TAIL, S.stream);
-            if (count) hipLaunchKernelGGL(k_tail<true>, dim3(traceGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
-            else hipLaunchKernelGGL(k_tail<false>, dim3(traceGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+            if (count) hipLaunchKernelGGL(k_tail<true>, dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+            else hipLaunchKernelGGL(k_tail<false>, dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
             tm.end(S.stream);
             st.launches[TRT_K_TAIL]++;
             S.n_active = 0;
