@@ -192,15 +192,27 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
 // This is the reference's own visit set — both children, no culling by the best hit (bvh.cpp:146-175) —
 // so the counters equal the oracle's, and the result is the same as the ordered traversal's because
 // the leaf rule and the between-leaves rule are applied unchanged.
+// Deferred divisions: a candidate triangle (acceptance test passed, t = tn / det not formed yet) is parked in a
+// small per-lane LDS queue [slot][lane]; the division, the t < 0.0005 cut and the fold into the best hit run
+// once per queue slot at the end of the ray (or when a lane's queue is full) instead of once per triangle that
+// ANY lane of the wave is a candidate for — with 64 incoherent rays that is nearly every triangle, while one
+// ray has only a few candidates.  The fold is interactBVHNode's and traverseBVH's two-level rule (bvh.cpp:219,
+// 168-172) in one step per candidate: nearer wins; at equal distance a candidate of the SAME leaf as the
+// current best (best index inside the candidate's leaf range; candidates arrive in index order) wins iff it is
+// emissive, one of ANOTHER leaf by "leftmost emissive, else rightmost" — what the leaf-local fold followed by
+// the between-leaves merge yields, since the leaves are disjoint index ranges.
+constexpr int TRT_PEND_SLOTS = 4;
 template <bool SHADOW, bool COUNT, bool PRIMARY>
 __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
-                                                  const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, DeviceStats* stats, bool any_flag)
+                                                  const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, DeviceStats* stats, bool any_flag,
+                                                  f4* __restrict__ pend)
 {
     const bool any = SHADOW && any_flag;  // occlusion test (TRT_FLAG_FIXED_NEE): the ray carries its own t_max in rb.w
     uint32_t n_inner = 0, n_tri = 0;
     const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
     const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
     const uint32_t n_nodes = sc.n_nodes;
+    f4* my_pend = pend + threadIdx.x;  // slot s of this lane: my_pend[s * TRT_TRACE_BLOCK]
     for (uint32_t base = lb * TRT_TRACE_BLOCK; base < n; base += stride) {
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < n;
@@ -213,6 +225,30 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
         float best_t = any ? b.w : TRT_INF;
         int32_t best_tri = -1;
         uint32_t best_flags = 0u;
+        uint32_t n_pend = 0;
+        // division + cut + fold of every parked candidate, slot by slot (= in the order they were found)
+        auto flush = [&]() {
+            for (uint32_t s = 0; __ballot(s < n_pend) != 0ull; ++s) {
+                if (s < n_pend) {
+                    const f4 e = my_pend[s * TRT_TRACE_BLOCK];
+                    const float t = e.x / e.y;
+                    if (!(t < TRT_T_MIN)) {  // bvh.cpp:189
+                        const int32_t j = (int32_t)f2u(e.z);
+                        const uint32_t leaf = f2u(e.w);
+                        const uint32_t fl = f2u(sc.tri_isect[j].c.z);
+                        bool take = t < best_t;
+                        if (t == best_t && best_tri >= 0) {
+                            const bool em = (fl & 1u) != 0, bem = (best_flags & 1u) != 0;
+                            const uint32_t first = TRT_LEAF_FIRST(leaf), cnt = TRT_LEAF_COUNT(leaf);
+                            const bool same_leaf = (uint32_t)best_tri >= first && (uint32_t)best_tri < first + cnt;
+                            take = same_leaf ? em : (em ? (!bem || j < best_tri) : (!bem && j > best_tri));
+                        }
+                        if (take) { best_t = t; best_tri = j; best_flags = fl; }
+                    }
+                }
+            }
+            n_pend = 0;
+        };
         for (uint32_t ni = 0; ni < n_nodes; ++ni) {
             const bool at = (reach >> ni) & 1u;
             if (__ballot(at) == 0ull) continue;
@@ -233,29 +269,22 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
                 }
                 if (__ballot(hc[c]) == 0ull) continue;
                 const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
-                float lt = TRT_INF;  // interactBVHNode (bvh.cpp:211-229): index order, local fold
-                int32_t li = -1;
-                uint32_t lflags = 0u;
-                for (uint32_t k = 0; k < count; ++k) {
+                for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
                     const TriIsect T = sc.tri_isect[first + k];  // wave-uniform address
                     if (COUNT && hc[c]) n_tri++;
-                    float t, un, vn, det;
-                    if (triTest(T, o, d, t, un, vn, det) && hc[c]) {
-                        const uint32_t fl = f2u(T.c.z);
-                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)(first + k); lflags = fl; }
+                    float tn, un, vn, det;
+                    // det > 0, so tn <= 0 gives t <= 0 < 0.0005 (and a NaN tn a NaN t, which no comparison accepts):
+                    // hits behind the origin, half of all candidates, are not parked at all
+                    const bool cand = triCandidate(T, o, d, tn, un, vn, det) && hc[c];
+                    if (__ballot(cand && n_pend == (uint32_t)TRT_PEND_SLOTS) != 0ull) flush();  // a full queue: empty all of them first
+                    if (cand) {
+                        my_pend[n_pend * TRT_TRACE_BLOCK] = mk4(tn, det, u2f(first + k), u2f(ref));
+                        n_pend++;
                     }
-                }
-                if (li >= 0) {
-                    bool take = lt < best_t;
-                    if (lt == best_t && best_tri >= 0) {  // equal distance across leaves (bvh.cpp:168-172, order independent form)
-                        const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
-                        take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
-                    }
-                    if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
-                    if (any && best_tri >= 0) reach = 0u;  // occluded: this lane is done with the tree
                 }
             }
         }
+        flush();
         if (valid) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
     }
     if (COUNT) {
@@ -478,7 +507,7 @@ __device__ __forceinline__ void traceQueue(const SceneDev& sc, const RaySource& 
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
 {
-    if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats, any_flag);
+    if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats, any_flag, reinterpret_cast<f4*>(smem));
     else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
     else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
 }
@@ -489,7 +518,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
-    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : DEPTH * TRT_TRACE_BLOCK];  // stack, or (uniform walk) the candidate queue
     traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false);
 }
 
@@ -501,7 +530,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any)
 {
-    __shared__ uint32_t smem[DEPTH * TRT_TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;

@@ -202,7 +202,9 @@ TRT_HD inline TriIsect makeTriIsect(const float* v9, int32_t mat, bool emissive)
 // with det made positive by flipping the signs of all four scalars.  Returns
 // true for a hit; t = tn/det is formed only then, and the barycentrics
 // u = un/det, v = vn/det are left to the caller (needed once per ray).
-TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& un_out, float& vn_out, float& det_out)
+// triCandidate: everything up to the acceptance test; tn, un, vn, det are the numerators / the denominator
+// (det > 0) of t, u, v.  triTest = triCandidate + the division + the t < 0.0005 cut.
+TRT_HD inline bool triCandidate(const TriIsect& T, f3 o, f3 d, float& tn_out, float& un_out, float& vn_out, float& det_out)
 {
     const float v0x = T.a.x, v0y = T.a.y, v0z = T.a.z;
     const float e1x = T.a.w, e1y = T.b.x, e1z = T.b.y;
@@ -226,14 +228,19 @@ TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& u
     const float rest = det - (un + vn);
     const uint32_t bu = f2u(un) - 1u, bv = f2u(vn) - 1u, br = f2u(rest) - 1u;
     const uint32_t bmax = bu > bv ? (bu > br ? bu : br) : (bv > br ? bv : br);
-    const bool cand = !(det < T.c.y) && bmax < 0x7F800000u;
-    if (!cand) return false;
-    const float t = tn / det;
-    if (t < TRT_T_MIN) return false;  // bvh.cpp:189
-    t_out = t;
+    tn_out = tn;
     un_out = un;
     vn_out = vn;
     det_out = det;
+    return !(det < T.c.y) && bmax < 0x7F800000u;
+}
+TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& un_out, float& vn_out, float& det_out)
+{
+    float tn;
+    if (!triCandidate(T, o, d, tn, un_out, vn_out, det_out)) return false;
+    const float t = tn / det_out;
+    if (t < TRT_T_MIN) return false;  // bvh.cpp:189
+    t_out = t;
     return true;
 }
 
