@@ -273,8 +273,6 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
                     const TriIsect T = sc.tri_isect[first + k];  // wave-uniform address
                     if (COUNT && hc[c]) n_tri++;
                     float tn, un, vn, det;
-                    // det > 0, so tn <= 0 gives t <= 0 < 0.0005 (and a NaN tn a NaN t, which no comparison accepts):
-                    // hits behind the origin, half of all candidates, are not parked at all
                     const bool cand = triCandidate(T, o, d, tn, un, vn, det) && hc[c];
                     if (__ballot(cand && n_pend == (uint32_t)TRT_PEND_SLOTS) != 0ull) flush();  // a full queue: empty all of them first
                     if (cand) {
