@@ -135,7 +135,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
                     const f3 w = cx.beta * contrib;
                     r_sh++;
                     // k_trace_shadow
-                    const Hit sh = traceClosest<ArrayStack, false>(hs.sc, cx.vx.P, wo, stk, ni, nt, t_max, fixed);
+                    const Hit sh = traceClosest<ArrayStack, false>(hs.sc, cx.vx.P, wo, stk, ni, nt, t_max, fixed, !fixed);
                     if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)hs.sc.lights[li].mat)) L = L + w;
                 }
                 f4 nra, nrb, nbt;

@@ -310,7 +310,7 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySo
         f4 a, b;
         fetchRay<PRIMARY>(sc, src, i, a, b);
         const bool any = SHADOW && any_flag;
-        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri, any ? b.w : TRT_INF, any);
+        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
         if (!SHADOW) {
             hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
         } else if (any ? h.tri < 0 : (h.tri >= 0 && (h.flags >> 8) == light_mat)) {
@@ -384,7 +384,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                     d = mk3(a.w, b.x, b.y);
                     if (SHADOW) pid = f2u(b.z);
                     inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    best_t = any ? b.w : TRT_INF; best_tri = -1; best_flags = 0u;
+                    best_t = SHADOW ? b.w : TRT_INF; best_tri = -1; best_flags = 0u;  // shadow rays carry a bound: t_max (any) or a search hint
                     sp = 0;
                     cur = 0u;  // nodes[0] is always an inner node
                     lk = 0; lt = TRT_INF; li = -1;
@@ -404,8 +404,9 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
                 if (!innerStep(sc, cur, sp, stk, o, inv, best_t)) {
-                    if (sp == 0) cur = TRT_REF_DONE;
-                    else cur = stk.pop(--sp);
+                    if (sp != 0) cur = stk.pop(--sp);
+                    else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }  // nothing in front of the hint: search again without it
+                    else cur = TRT_REF_DONE;
                 }
             }
         }
@@ -437,8 +438,10 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                     }
                     if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
                 }
-                if (sp == 0 || (any && best_tri >= 0)) cur = TRT_REF_DONE;
-                else cur = stk.pop(--sp);
+                if (any && best_tri >= 0) cur = TRT_REF_DONE;
+                else if (sp != 0) cur = stk.pop(--sp);
+                else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }
+                else cur = TRT_REF_DONE;
             }
             if (COUNT && lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_tri++;
         }
@@ -483,8 +486,10 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             }
         }
         if (adv) {
-            if (sp == 0 || (any && best_tri >= 0)) cur = TRT_REF_DONE;
-            else cur = stk.pop(--sp);
+            if (any && best_tri >= 0) cur = TRT_REF_DONE;
+            else if (sp != 0) cur = stk.pop(--sp);
+            else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }  // nothing in front of the hint: search again without it
+            else cur = TRT_REF_DONE;
             lk = 0; lt = TRT_INF; li = -1;
         }
         }
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
                 if (!c.shade_ok || !lightSample(sc, c.vx, *c.m, li, c.rng, wo, contrib, fixed, t_max)) continue;
                 const f3 w = c.beta * contrib;
                 n_shadow++;
-                const Hit sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1], t_max, fixed);
+                const Hit sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1], t_max, fixed, !fixed);
                 if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)sc.lights[li].mat)) { L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z; }
             }
             f4 nra, nrb, nbt;

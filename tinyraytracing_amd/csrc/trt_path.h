@@ -339,12 +339,16 @@ TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& 
 template <class Stack, bool COUNT>
 // `t_init` bounds the search (only hits STRICTLY nearer count) and `any` stops at the first leaf that yields
 // one: together they make the occlusion test of TRT_FLAG_FIXED_NEE (tri >= 0 <=> something lies in front of t_init).
-TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false)
+// `redo`: t_init is only a hint — a hit in front of it is the closest hit of the whole scene (anything nearer than the
+// bound beats everything beyond it, ties included), and when there is none the search runs again without the bound.
+TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false,
+                               bool redo = false)
 {
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     Hit best;
     best.t = t_init; best.tri = -1; best.u = 0.f; best.v = 0.f; best.flags = 0u;
     float best_det = 1.0f;  // best.u / best.v hold the numerators un, vn until the end
+  for (;;) {  // once; twice when `redo` and nothing lies in front of t_init
     int sp = 0;
     uint32_t cur = 0;  // nodes[0] is always an inner node
     for (;;) {
@@ -394,6 +398,9 @@ TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
             cur = stk.pop(--sp);
         }
     }
+    if (!redo || best.tri >= 0 || !(best.t < TRT_INF)) break;
+    best.t = TRT_INF;
+  }
     if (best.tri >= 0) {  // barycentric weights of v1, v2 (the values findBaryCor feeds bvh.cpp:224)
         best.u = best.u / best_det;
         best.v = best.v / best_det;
@@ -532,7 +539,9 @@ TRT_HD inline Vertex makeVertex(const SceneDev& sc, const Hit& h, f3 o, f3 d, co
 // hit carries the light's material (pathTracing.cpp:55-70).
 // `fixed` (TRT_FLAG_FIXED_NEE): the CDF draw spans this light's own area (not Q3), the point is uniform on the
 // triangle (not Q4), and `t_max` = 0.999 |x' - x| bounds the occlusion test that replaces the closest-hit +
-// material comparison (not Q5); t_max is TRT_INF in parity mode.
+// material comparison (not Q5).  In parity mode t_max = 1.001 |x' - x| is only a search hint for the closest-hit
+// query (traceClosest's `redo`): the light's own triangle lies inside it, so the bounded search almost always
+// finds the closest hit at once, having culled everything beyond the light.
 TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const MaterialDev& m, uint32_t li, Stream& rng, f3& wo, f3& contrib, bool fixed, float& t_max)
 {
     const LightDev L = sc.lights[li];
@@ -569,7 +578,7 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
     wo = normalize(diff);
     const float cos_s = dot(wo, vx.pn);
     if (!(cos_s > 0.0f)) return false;  // pathTracing.cpp:60: such a sample never contributes
-    t_max = fixed ? 0.999f * length(diff) : TRT_INF;
+    t_max = (fixed ? 0.999f : 1.001f) * length(diff);
     const float pdf_light = L.pdf;  // 1 / area, makeLightDev
     const float cos_theta_p = fabsf(dot(wo, light_n));
     const float cos_theta = fabsf(cos_s / length(vx.pn));
