@@ -156,7 +156,7 @@ typedef struct trt_params {
     int32_t row_block, row_mod, row_rem;
     int32_t max_depth;       /* 0 = unbounded like the reference (pathTracing.cpp:78-99) */
     uint32_t flags;
-    uint64_t mem_budget;     /* bytes of HBM for path/queue state; 0 = default */
+    uint64_t mem_budget;     /* bytes of HBM for path/queue state; 0 = three quarters of what is free (one pass when it fits) */
 } trt_params;
 
 #define TRT_MAX_KERNELS 8
