@@ -247,6 +247,31 @@ def test_config3_soup_tile_vs_oracle(renderer_factory):
         assert st.rays == ost.rays
 
 
+def test_config5_ten_million_triangles_at_4k_tile_vs_oracle():
+    """Config 5's scene at full size — 10 M triangles, 3840 x 2160 — through the binned-SAH builder, the wide-node
+    collapse, the spilling stack and the scheduler driver: tiles against the oracle (which walks the same tree),
+    and full-frame properties (every camera ray accounted for; two renders bit-identical)."""
+    s = T.Scene.named("blob", 3840, 2160, n=10_000_000)
+    assert s.info["n_triangles"] >= 10_000_000
+    r = T.Renderer(s, 0)
+    try:
+        for (x0, y0) in ((1900, 1000), (2300, 1500), (40, 2100)):
+            pt = T.make_params(3840, 2160, 16, T.SEED_BLOB, tile=(x0, y0, x0 + 16, y0 + 8))
+            img, st = r.render(pt)
+            ref, ost = O.render(s.flat, pt)
+            assert_same_image(img, ref, f"blob-10M tile {x0},{y0}")
+            assert st.rays == ost.rays
+        full = T.make_params(3840, 2160, 2, T.SEED_BLOB)
+        a, sa = r.render(full)
+        b, sb = r.render(full)
+        assert sa.rays_camera == 3840 * 2160 * 2 and sa.rays == sb.rays
+        assert np.array_equal(a, b) and np.isfinite(a).all() and a.max() > 0
+        assert np.array_equal(a[1000:1008, 1900:1916], r.render(T.make_params(3840, 2160, 2, T.SEED_BLOB, tile=(1900, 1000, 1916, 1008)))[0])
+    finally:
+        r.close()
+        s.close()
+
+
 def test_config4_staircase_tile_at_1024spp_vs_oracle(renderer_factory):
     """Config 4 (largest cg22 scene, 1920x1080, 1024 spp): tiles of the full-size frame against the oracle.
     6 lights (Q3 CDF quirk), 3 textures, glass (Fresnel / TIR), Phong lobes up to Ns = 1000."""
