@@ -6,7 +6,7 @@
 //   ray queue   ra = (o.x, o.y, o.z, d.x)   rb = (d.y, d.z, bits(path id), bits(meta))
 //               bt = (beta.r, beta.g, beta.b, -)
 //   hit buffer  (t, bits(tri), u, v)
-//   shadow queue per light   sa = (o.xyz, d.x)  sb = (d.y, d.z, bits(path id), -)
+//   shadow queue per light   sa = (o.xyz, d.x)  sb = (d.y, d.z, bits(path id), t_max: search hint / occlusion range)
 //                            sw = (w.r, w.g, w.b, -)   w = beta * unoccluded contribution
 //   accumulator Lacc[path id] = (L.r, L.g, L.b, -)
 // Bounce 0 generates its camera rays in registers (no queue).  Per bounce: trace_closest -> shade (emits <= 1 extension ray and <= 1 shadow
@@ -16,7 +16,8 @@
 //
 // Traversal stack: per-lane stack of node references in LDS, laid out
 // [level][lane] so a wave's accesses hit 64 consecutive banks; levels beyond
-// the kernel's LDS depth (8 / 16 / 24 / 32 levels; 32 + spill when the scene's BVH is deeper) spill to a per-thread global area.
+// the kernel's LDS depth (8 or 16 levels; 16 + spill when the wide tree can need more) spill to a per-thread
+// global area.  The per-lane traversals walk 4-wide nodes (trt_wide.h); tiny scenes are walked wave-uniformly.
 #pragma once
 #include <hip/hip_runtime.h>
 
