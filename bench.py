@@ -180,6 +180,11 @@ def main():
                     "avg_launch_ms": round(dom_ms / max(launches[dom], 1), 5),
                     "algorithmic_bytes_per_launch": int(dom_bytes_step * a.steps / max(launches[dom], 1)),
                     "frac_of_measured_copy_peak": round(achieved / 6290.0, 4)}
+        if traffic and launches[dom] and dom_ms > 0:
+            # the same launches' measured HBM-side bytes (PMC passes, profiles/) over the live launch duration
+            meas = traffic / (dom_ms / launches[dom] * 1e-3) / 1e9
+            roofline["traffic_GBps"] = round(meas, 1)
+            roofline["traffic_frac"] = round(meas / HBM_PEAK_GBS, 4)
         if achieved > HBM_PEAK_GBS:
             roofline["note"] = ("algorithmic bytes (every node / triangle record a ray touches) exceed the HBM peak because the scene is "
                                 "served from L1/L2/Infinity Cache; the kernel is bound by VALU issue and the L1 tag rate, not by HBM (DESIGN.md 5)")
