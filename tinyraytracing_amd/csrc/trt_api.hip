@@ -319,6 +319,9 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     h->device = device;
     h->bvh2_depth = depth;
     if (const char* e = std::getenv("TRT_TAIL_N")) h->tail_n = (uint32_t)std::strtoul(e, nullptr, 10);
+    h->sc.refill_min = s->n_tris <= 200000u ? 48u : 32u;
+    if (const char* e = std::getenv("TRT_REFILL_MIN")) h->sc.refill_min = std::min(64u, std::max(1u, (uint32_t)std::strtoul(e, nullptr, 10)));
+    if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: refill_min %u tail_n %u\n", h->sc.refill_min, h->tail_n);
     if (const char* e = std::getenv("TRT_TRACE_RPW")) g_rays_per_wave = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TRT_TRACE_FILLB")) g_fill_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TRT_TRACE_MAXB")) g_max_blocks = std::max(8u, (uint32_t)std::strtoul(e, nullptr, 10));

@@ -133,11 +133,10 @@ __device__ inline unsigned long long waveSum(unsigned long long v)
 //      steps run until no lane holds an inner node, then all pending leaves are intersected
 //   3  persistent wave with a per-step scheduler: each iteration runs the step kind (inner node /
 //      one triangle) that more lanes are waiting for
-// TRT_REFILL_MIN (impl 2, 3): finished lanes are written back and refilled in batches of at least
-// this many lanes (ray set-up and result write-back then run at decent lane utilisation).
-#ifndef TRT_REFILL_MIN
-#define TRT_REFILL_MIN 16
-#endif
+// sc.refill_min (impl 2, 3): finished lanes are written back and refilled in batches of at least this many lanes:
+// ray set-up (three IEEE reciprocals) and result write-back (the winner's barycentrics) then run at decent lane
+// utilisation.  Chosen per scene in trt_create (TRT_REFILL_MIN in the environment overrides): short traversals
+// want large batches (staircase 454 -> 434 ms/step at 48 instead of 16), deep trees smaller ones (blob, soup: 32).
 
 // Where a traversal kernel takes ray `i` from: the queue in HBM, or (PRIMARY) the camera-ray generator.
 struct RaySource {
@@ -370,7 +369,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         const unsigned long long m_done = __ballot(cur == TRT_REF_DONE);
         const unsigned long long m_free = ~m_work;  // finished or empty lanes
         const bool can_fill = next < end;
-        if (m_work == 0ull || (m_done != 0ull && __popcll(can_fill ? m_free : m_done) >= TRT_REFILL_MIN)) {
+        if (m_work == 0ull || (m_done != 0ull && (uint32_t)__popcll(can_fill ? m_free : m_done) >= sc.refill_min)) {
             if (cur == TRT_REF_DONE) {
                 storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc, any);
                 cur = TRT_REF_IDLE;
