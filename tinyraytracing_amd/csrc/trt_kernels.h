@@ -450,7 +450,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         const bool is_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
         const unsigned long long m_in = __ballot(is_inner), m_lf = __ballot(is_leaf);
         bool adv = false;  // this lane is done with its node: take the next one off the stack, or finish the ray
-        if (__popcll(m_in) >= __popcll(m_lf)) {
+        if (sc.sched_in_w * (uint32_t)__popcll(m_in) >= sc.sched_lf_w * (uint32_t)__popcll(m_lf)) {
             // ---- inner-node step
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }

@@ -136,6 +136,7 @@ struct SceneDev {
     const uint8_t* tex_bytes;
     uint32_t n_tris, n_nodes, n_wnodes, n_lights;
     uint32_t refill_min;  // persistent traversal drivers: lanes to have free before a refill (trt_kernels.h)
+    uint32_t sched_in_w, sched_lf_w;  // scheduler driver: node step iff sched_in_w * (lanes at nodes) >= sched_lf_w * (lanes at leaves)
     float light0_area;  // Q3: every light's CDF draw spans lights[0].area (pathTracing.cpp:38)
     trt_camera cam;
 };
