@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -416,7 +418,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     h->spill_words_per_slot = (size_t)spill_levels * SPILL_STRIDE;
     if (int e = h->spill.ensure(h->spill_words_per_slot * 2 * sizeof(uint32_t))) return e;  // one area per concurrent pass
     for (hipStream_t& st : h->slot_streams) HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPC(hipHostMalloc((void**)&h->pinned_counts, 2 * 2 * COUNT_ROW * sizeof(uint32_t), hipHostMallocDefault));
+    HIPC(hipHostMalloc((void**)&h->pinned_counts, 2 * (2 * COUNT_ROW + 16) * sizeof(uint32_t), hipHostMallocDefault));  // per slot: counters + sequence word
     if (const char* e = std::getenv("TRT_SLOTS")) h->n_slots = std::atoi(e) >= 2 ? 2 : 1;
     *out = h.release();
     return TRT_OK;
@@ -443,7 +445,8 @@ struct PassSlot {
     f4* Lacc = nullptr;
     ShadowQueue SQ[TRT_MAX_LIGHTS];
     uint32_t* d_counts = nullptr;
-    uint32_t* host_counts = nullptr;  // pinned
+    uint32_t* host_counts = nullptr;  // pinned, device-visible: 2 * COUNT_ROW counters + the sequence word
+    uint32_t seq = 0;                 // last sequence number asked for
     uint32_t* spill = nullptr;
     enum State { IDLE, ISSUE, WAIT, RESOLVE } state = IDLE;
     uint32_t chunk = 0, s0 = 0, sc_count = 0, n_active = 0, b = 0;
@@ -535,7 +538,9 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         for (uint32_t l = 0; l < (uint32_t)TRT_MAX_LIGHTS; ++l) S.SQ[l] = ShadowQueue{nullptr, nullptr, nullptr};
         for (uint32_t l = 0; l < nl; ++l) { S.SQ[l].sa = take(); S.SQ[l].sb = take(); S.SQ[l].sw = take(); }
         S.d_counts = (uint32_t*)(sb + rows_bytes + counts_bytes * (size_t)k);
-        S.host_counts = h->pinned_counts + (size_t)k * 2 * COUNT_ROW;
+        S.host_counts = h->pinned_counts + (size_t)k * (2 * COUNT_ROW + 16);
+        S.host_counts[2 * COUNT_ROW] = 0;
+        S.seq = 0;
         S.spill = (uint32_t*)h->spill.p + (size_t)k * h->spill_words_per_slot;
     }
 
@@ -622,15 +627,27 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         hipLaunchKernelGGL(k_shade, dim3(std::min<uint32_t>((S.n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u)), dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A);
         tm.end(S.stream);
         st.launches[TRT_K_SHADE]++;
-        // (b, c) and (b + 1, c) of the counters in use -> host_counts[2 * c], [2 * c + 1]
-        HIPC(hipMemcpy2DAsync(S.host_counts, 2 * sizeof(uint32_t), S.d_counts + S.b, (size_t)COUNT_STRIDE * sizeof(uint32_t), 2 * sizeof(uint32_t), 1 + nl,
-                              hipMemcpyDeviceToHost, S.stream));
+        // (b, c) and (b + 1, c) of the counters in use -> host_counts[2 * c], [2 * c + 1], then the sequence word
+        S.seq++;
+        hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, S.stream, S.d_counts, COUNT_STRIDE, S.b, 1u + nl, (volatile uint32_t*)S.host_counts, S.seq);
         S.state = PassSlot::WAIT;
         return TRT_OK;
     };
     // queue lengths are back: shadow rays of this bounce, then the next bounce / the tail / the end of the pass
     auto completeBounce = [&](PassSlot& S) -> int {
-        HIPC(hipStreamSynchronize(S.stream));
+        {   // spin on the sequence word the device writes after the counters; the stream is the fallback (and the error path)
+            volatile uint32_t* flag = (volatile uint32_t*)S.host_counts + 2 * COUNT_ROW;
+            const auto t0 = std::chrono::steady_clock::now();
+            uint32_t spins = 0;
+            while (*flag != S.seq) {
+                if ((++spins & 0x3FFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                    HIPC(hipStreamSynchronize(S.stream));  // long kernels: let the runtime wait; also surfaces a device error
+                    if (*flag != S.seq) return fail(TRT_EHIP, "queue lengths did not arrive");
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         for (uint32_t l = 0; l < nl; ++l) {
             const uint32_t ns = S.host_counts[2 * (1 + l)];
             if (ns > S.n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");

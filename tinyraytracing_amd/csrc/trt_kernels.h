@@ -801,6 +801,21 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ acc
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)acc[i];
 }
 
+// The queue lengths of a bounce, pushed to the host: counters (b, c) and (b + 1, c), c = 0..n-1, into a pinned,
+// device-visible host buffer (out[2c], out[2c+1]), then a sequence number — the host spins on that word instead of
+// paying a DMA copy plus a stream-synchronise wake-up per bounce (one wave, launched behind k_shade).
+__global__ __launch_bounds__(64) void k_publish_counts(const uint32_t* __restrict__ counts, uint32_t stride, uint32_t b, uint32_t n,
+                                                        volatile uint32_t* out, uint32_t seq)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 2u * n) out[t] = counts[(size_t)(t >> 1) * stride + b + (t & 1u)];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_store(const_cast<uint32_t*>(out) + 2u * 16u, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ray-batch entry (trt_trace_closest): SoA repack of host org/dir arrays
 __global__ __launch_bounds__(256) void k_pack_rays(const float* __restrict__ org, const float* __restrict__ dir, f4* __restrict__ ra, f4* __restrict__ rb, uint32_t n)
 {

@@ -18,4 +18,4 @@ for label, flags in (("no flags", 0), ("TIMING", T.TRT_FLAG_TIMING), ("OVERLAP",
         st = r.render_into(p, out)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 3
-    print(f"{name} 1/{world} {label:9s} {dt*1e3:8.2f} ms/step  {st.rays/dt/1e6:9.1f} Mrays/s  device render_ms {st.render_ms:.2f}", flush=True)
+    print(f"{name} 1/{world} {label:9s} {dt*1e3:8.2f} ms/step  {st.rays/dt/1e6:9.1f} Mrays/s  device render_ms {st.render_ms:.2f}" + (f"  kernels {sum(st.kernel_ms):.2f} ms in {sum(st.launches)} launches, {st.passes} passes, deepest vertex {st.max_bounces}  " + " ".join(f"{T.KERNEL_NAMES[k]}={st.kernel_ms[k]:.2f}" for k in range(len(T.KERNEL_NAMES)) if st.kernel_ms[k] > 0) if flags & T.TRT_FLAG_TIMING else ""), flush=True)
