@@ -676,6 +676,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
             TA.max_depth = p->max_depth;
             TA.spill = S.spill;
             TA.spill_stride = SPILL_STRIDE;
+            TA.uniform = h->trace_impl == 0 ? 1u : 0u;
             TA.stats = d_stats;
             tm.begin(TRT_K_TAIL, S.stream);
             if (count) hipLaunchKernelGGL(k_tail<true>, dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);

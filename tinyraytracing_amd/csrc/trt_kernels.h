@@ -202,6 +202,75 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
 // emissive, one of ANOTHER leaf by "leftmost emissive, else rightmost" — what the leaf-local fold followed by
 // the between-leaves merge yields, since the leaves are disjoint index ranges.
 constexpr int TRT_PEND_SLOTS = 4;
+// The walk itself for the rays the active lanes of a wave hold (`valid`: this lane has one).  best_t comes in as the
+// bound of the search (TRT_INF, or an occlusion range) and goes out with best_tri / best_flags as the closest hit.
+template <bool COUNT>
+__device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool valid, f4* __restrict__ my_pend, float& best_t, int32_t& best_tri,
+                                            uint32_t& best_flags, uint32_t& n_inner, uint32_t& n_tri)
+{
+    const uint32_t n_nodes = sc.n_nodes;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t reach = valid ? 1u : 0u;  // bit k: the ray reaches inner node k
+    uint32_t n_pend = 0;
+    // division + cut + fold of every parked candidate, slot by slot (= in the order they were found)
+    auto flush = [&]() {
+        for (uint32_t s = 0; __ballot(s < n_pend) != 0ull; ++s) {
+            if (s < n_pend) {
+                const f4 e = my_pend[s * TRT_TRACE_BLOCK];
+                const float t = e.x / e.y;
+                if (!(t < TRT_T_MIN)) {  // bvh.cpp:189
+                    const int32_t j = (int32_t)f2u(e.z);
+                    const uint32_t leaf = f2u(e.w);
+                    const uint32_t fl = f2u(sc.tri_isect[j].c.z);
+                    bool take = t < best_t;
+                    if (t == best_t && best_tri >= 0) {
+                        const bool em = (fl & 1u) != 0, bem = (best_flags & 1u) != 0;
+                        const uint32_t first = TRT_LEAF_FIRST(leaf), cnt = TRT_LEAF_COUNT(leaf);
+                        const bool same_leaf = (uint32_t)best_tri >= first && (uint32_t)best_tri < first + cnt;
+                        take = same_leaf ? em : (em ? (!bem || j < best_tri) : (!bem && j > best_tri));
+                    }
+                    if (take) { best_t = t; best_tri = j; best_flags = fl; }
+                }
+            }
+        }
+        n_pend = 0;
+    };
+    for (uint32_t ni = 0; ni < n_nodes; ++ni) {
+        const bool at = (reach >> ni) & 1u;
+        if (__ballot(at) == 0ull) continue;
+        const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + ni);  // wave-uniform address
+        const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
+        if (COUNT && at) n_inner++;
+        float e0, e1;
+        const bool h0 = at && boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
+        const bool h1 = at && boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
+        const uint32_t child[2] = {f2u(q3.x), f2u(q3.y)};
+        const bool hc[2] = {h0, h1};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t ref = child[c];
+            if (!(ref & TRT_LEAF_BIT)) {
+                reach |= hc[c] ? (1u << ref) : 0u;
+                continue;
+            }
+            if (__ballot(hc[c]) == 0ull) continue;
+            const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
+            for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
+                const TriIsect T = sc.tri_isect[first + k];  // wave-uniform address
+                if (COUNT && hc[c]) n_tri++;
+                float tn, un, vn, det;
+                const bool cand = triCandidate(T, o, d, tn, un, vn, det) && hc[c];
+                if (__ballot(cand && n_pend == (uint32_t)TRT_PEND_SLOTS) != 0ull) flush();  // a full queue: empty all of them first
+                if (cand) {
+                    my_pend[n_pend * TRT_TRACE_BLOCK] = mk4(tn, det, u2f(first + k), u2f(ref));
+                    n_pend++;
+                }
+            }
+        }
+    }
+    flush();
+}
+
 template <bool SHADOW, bool COUNT, bool PRIMARY>
 __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                                   const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, DeviceStats* stats, bool any_flag,
@@ -211,7 +280,6 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
     uint32_t n_inner = 0, n_tri = 0;
     const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
     const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
-    const uint32_t n_nodes = sc.n_nodes;
     f4* my_pend = pend + threadIdx.x;  // slot s of this lane: my_pend[s * TRT_TRACE_BLOCK]
     for (uint32_t base = lb * TRT_TRACE_BLOCK; base < n; base += stride) {
         const uint32_t i = base + threadIdx.x;
@@ -220,69 +288,10 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
         f4 a, b;
         fetchRay<PRIMARY>(sc, src, ii, a, b);
         const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        uint32_t reach = valid ? 1u : 0u;  // bit k: the ray reaches inner node k
         float best_t = any ? b.w : TRT_INF;
         int32_t best_tri = -1;
         uint32_t best_flags = 0u;
-        uint32_t n_pend = 0;
-        // division + cut + fold of every parked candidate, slot by slot (= in the order they were found)
-        auto flush = [&]() {
-            for (uint32_t s = 0; __ballot(s < n_pend) != 0ull; ++s) {
-                if (s < n_pend) {
-                    const f4 e = my_pend[s * TRT_TRACE_BLOCK];
-                    const float t = e.x / e.y;
-                    if (!(t < TRT_T_MIN)) {  // bvh.cpp:189
-                        const int32_t j = (int32_t)f2u(e.z);
-                        const uint32_t leaf = f2u(e.w);
-                        const uint32_t fl = f2u(sc.tri_isect[j].c.z);
-                        bool take = t < best_t;
-                        if (t == best_t && best_tri >= 0) {
-                            const bool em = (fl & 1u) != 0, bem = (best_flags & 1u) != 0;
-                            const uint32_t first = TRT_LEAF_FIRST(leaf), cnt = TRT_LEAF_COUNT(leaf);
-                            const bool same_leaf = (uint32_t)best_tri >= first && (uint32_t)best_tri < first + cnt;
-                            take = same_leaf ? em : (em ? (!bem || j < best_tri) : (!bem && j > best_tri));
-                        }
-                        if (take) { best_t = t; best_tri = j; best_flags = fl; }
-                    }
-                }
-            }
-            n_pend = 0;
-        };
-        for (uint32_t ni = 0; ni < n_nodes; ++ni) {
-            const bool at = (reach >> ni) & 1u;
-            if (__ballot(at) == 0ull) continue;
-            const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + ni);  // wave-uniform address
-            const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
-            if (COUNT && at) n_inner++;
-            float e0, e1;
-            const bool h0 = at && boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
-            const bool h1 = at && boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
-            const uint32_t child[2] = {f2u(q3.x), f2u(q3.y)};
-            const bool hc[2] = {h0, h1};
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const uint32_t ref = child[c];
-                if (!(ref & TRT_LEAF_BIT)) {
-                    reach |= hc[c] ? (1u << ref) : 0u;
-                    continue;
-                }
-                if (__ballot(hc[c]) == 0ull) continue;
-                const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
-                for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
-                    const TriIsect T = sc.tri_isect[first + k];  // wave-uniform address
-                    if (COUNT && hc[c]) n_tri++;
-                    float tn, un, vn, det;
-                    const bool cand = triCandidate(T, o, d, tn, un, vn, det) && hc[c];
-                    if (__ballot(cand && n_pend == (uint32_t)TRT_PEND_SLOTS) != 0ull) flush();  // a full queue: empty all of them first
-                    if (cand) {
-                        my_pend[n_pend * TRT_TRACE_BLOCK] = mk4(tn, det, u2f(first + k), u2f(ref));
-                        n_pend++;
-                    }
-                }
-            }
-        }
-        flush();
+        uniformWalk<COUNT>(sc, o, d, valid, my_pend, best_t, best_tri, best_flags, n_inner, n_tri);
         if (valid) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
     }
     if (COUNT) {
@@ -716,13 +725,15 @@ struct TailArgs {
     int32_t max_depth;
     uint32_t* spill;
     uint32_t spill_stride;
+    uint32_t uniform;  // tiny scene: traverse with the wave-uniform walk (scalar loads) instead of the per-lane stack
     DeviceStats* stats;
 };
 
 template <bool COUNT>
 __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs A)
 {
-    __shared__ uint32_t smem[TRT_LDS_STACK_MAX * TRT_TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[TRT_LDS_STACK_MAX * TRT_TRACE_BLOCK];  // the stacks, or (uniform) the candidate queues
+    static_assert(TRT_LDS_STACK_MAX >= TRT_PEND_SLOTS * 4, "candidate queue must fit the stack area");
     LdsStack<TRT_LDS_STACK_MAX, true> stk;
     stk.lds = smem + threadIdx.x;
     stk.spill = A.spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
@@ -737,7 +748,18 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
         const uint32_t pid = f2u(rb.z);
         f4 L = A.Lacc[pid];
         for (;;) {
-            const Hit h = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni[0], nt[0]);
+            Hit h;
+            if (A.uniform) {  // the few rays still alive are bound by the latency of a bounce: no per-lane gathers, no stack
+                const f3 o = mk3(ra.x, ra.y, ra.z), d = mk3(ra.w, rb.x, rb.y);
+                h.t = TRT_INF; h.tri = -1; h.flags = 0u; h.u = 0.f; h.v = 0.f;
+                uniformWalk<COUNT>(sc, o, d, true, reinterpret_cast<f4*>(smem) + threadIdx.x, h.t, h.tri, h.flags, ni[0], nt[0]);
+                if (h.tri >= 0) {
+                    float t, un, vn, det;
+                    if (triTest(sc.tri_isect[h.tri], o, d, t, un, vn, det)) { h.u = un / det; h.v = vn / det; }
+                }
+            } else {
+                h = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni[0], nt[0]);
+            }
             ShadeCtx c;
             shadeBegin(sc, A.td, A.s0, ra, rb, bt, mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v), c);
             if (c.had_hit) { any = true; deepest = c.depth > deepest ? c.depth : deepest; }
@@ -750,7 +772,13 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
                 if (!c.shade_ok || !lightSample(sc, c.vx, *c.m, li, c.rng, wo, contrib, fixed, t_max)) continue;
                 const f3 w = c.beta * contrib;
                 n_shadow++;
-                const Hit sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1], t_max, fixed, !fixed);
+                Hit sh;
+                if (A.uniform) {
+                    sh.t = fixed ? t_max : TRT_INF; sh.tri = -1; sh.flags = 0u; sh.u = 0.f; sh.v = 0.f;
+                    uniformWalk<COUNT>(sc, c.vx.P, wo, true, reinterpret_cast<f4*>(smem) + threadIdx.x, sh.t, sh.tri, sh.flags, ni[1], nt[1]);
+                } else {
+                    sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1], t_max, fixed, !fixed);
+                }
                 if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)sc.lights[li].mat)) { L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z; }
             }
             f4 nra, nrb, nbt;
