@@ -87,7 +87,7 @@ struct alignas(16) MaterialDev {
     float sel_kdks;   // sel_kd + |Ks| / (|Kd| + |Ks|)
     float rf0;        // ((n1 - n2) / (n1 + n2))^2     (Schlick, pathTracing.cpp:157-160; the same either way)
     float Ni_inv;     // 1 / Ni
-    int32_t pad;
+    int32_t no_spec;  // the Phong term of lightSample() is exactly zero for this material and need not be evaluated
 };
 static_assert(sizeof(MaterialDev) == 96, "MaterialDev must be six 16-byte words");
 // trt_light_tri (19 floats) padded to 80 B
@@ -162,7 +162,14 @@ TRT_HD inline MaterialDev makeMaterialDev(const trt_material& m)
     const float q = (1.0f - m.Ni) / (1.0f + m.Ni);  // (Ni - 1) / (Ni + 1) is its exact negative: one square serves both sides
     d.rf0 = q * q;
     d.Ni_inv = 1.0f / m.Ni;
-    d.pad = 0;
+    // Ks == 0 (either sign) makes the term +-0 whenever pow01 is finite, i.e. for 0 < Ns < inf; adding -0 never changes
+    // kd_pi, adding +0 changes only a -0 component: excluded.  Textured materials (kd_pi from texels, >= +0) qualify too.
+    bool no_spec = m.Ns > 0.0f && m.Ns < 3.0e38f;
+    for (int k = 0; k < 3; ++k) {
+        const bool ks_pos_zero = f2u(m.Ks[k]) == 0u, ks_neg_zero = f2u(m.Ks[k]) == 0x80000000u;
+        no_spec = no_spec && (ks_neg_zero || (ks_pos_zero && f2u(d.Kd_pi[k]) != 0x80000000u));
+    }
+    d.no_spec = no_spec ? 1 : 0;
     return d;
 }
 TRT_HD inline LightTriDev makeLightTriDev(const trt_light_tri& t)
@@ -586,12 +593,21 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
     const float cos_theta = fabsf(cos_s / length(vx.pn));
     const f3 radiance = ld3(L.radiance);
     const f3 intensity = (((radiance * cos_theta_p) * cos_theta) / dot(diff, diff)) / pdf_light;
-    const f3 hv = normalize((vx.wi + wo) * 0.5f);
-    const float ca = dot(vx.pn, hv);
-    const float cos_alpha = ca > 0.0f ? ca : 0.0f;
-    const float pw = trt_pow01(cos_alpha, m.Ns);
-    const f3 spec = ((ld3(m.Ks) * (m.Ns + 2.0f)) * pw) / (2.0f * TRT_PI);
-    const f3 brdf = (m.tex >= 0 ? vx.Kd / TRT_PI : ld3(m.Kd_pi)) + spec;
+    const f3 kd_pi = m.tex >= 0 ? vx.Kd / TRT_PI : ld3(m.Kd_pi);
+    f3 brdf;
+    if (m.no_spec) {
+        // Ks = 0 and 0 < Ns < inf: cos_alpha is in [0, 1] (never NaN), pow01 there is finite, so the Phong term
+        // ((Ks (Ns+2)) pw) / 2pi is exactly +-0 and kd_pi + it is kd_pi (makeMaterialDev rules out the one case
+        // -0 + +0 where it would not be): the half vector, the power and three divisions are not evaluated at all.
+        brdf = kd_pi;
+    } else {
+        const f3 hv = normalize((vx.wi + wo) * 0.5f);
+        const float ca = dot(vx.pn, hv);
+        const float cos_alpha = ca > 0.0f ? ca : 0.0f;
+        const float pw = trt_pow01(cos_alpha, m.Ns);
+        const f3 spec = ((ld3(m.Ks) * (m.Ns + 2.0f)) * pw) / (2.0f * TRT_PI);
+        brdf = kd_pi + spec;
+    }
     contrib = intensity * brdf;
     return true;
 }
