@@ -491,7 +491,11 @@ TRT_HD inline int nextRay(const MaterialDev& m, f3 pn, f3 I, Stream& rng, f3& ou
         }
     }
     const float kd = m.sel_kd, kdks = m.sel_kdks;  // |Kd| / (|Kd| + |Ks|) and that + |Ks| / (|Kd| + |Ks|), makeMaterialDev
-    const float p = rng.next();
+    // the lobe draw p lies in [0, 1): a purely diffuse material (kd == 1) takes the diffuse lobe whatever p is, so the
+    // draw is only counted there, not generated
+    float p = 0.0f;
+    if (kd >= 1.0f) rng.ctr++;
+    else p = rng.next();
     if (p < kd) {
         const float u_phi = rng.next(), u_theta = rng.next();
         out = sampleDir(pn, TRT_RAY_DIFFUSE, m.Ns, u_phi, u_theta);
