@@ -198,7 +198,7 @@ def main():
             "dtype": "f32", "data": f"scene '{a.scene}' ({WORKLOADS[a.scene]}), counter RNG seed {seed:#x}",
             "config": {"workload": f"{WORKLOADS[a.scene]}, {a.width}x{a.height}, {a.spp} spp", "scene": a.scene, "width": a.width,
                        "height": a.height, "spp": a.spp, "triangles": scene.info["n_triangles"], "bvh_nodes": scene.arrays()["n_nodes"],
-                       "leaf_num": a.leaf if a.leaf is not None else (T.TINY_LEAF if scene.info["n_triangles"] <= 64 else T.DEFAULT_LEAF), "overlap_passes": bool(a.overlap), "fixed_nee": bool(a.fixed_nee), "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
+                       "leaf_num": a.leaf if a.leaf is not None else T.default_leaf(a.scene, scene.info["n_triangles"]), "overlap_passes": bool(a.overlap), "fixed_nee": bool(a.fixed_nee), "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
             "rays_per_step": rays_total // a.steps,
             "rays_rank0": {"camera": st.rays_camera, "shadow": st.rays_shadow, "indirect": st.rays_indirect},
             "device_render_ms_per_step_rank0": round(render_ms / a.steps, 3),
