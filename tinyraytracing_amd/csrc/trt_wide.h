@@ -10,7 +10,8 @@
 // drop NaNs the same way for both), so "passes C" implies "passes P" and entry(P) <= entry(C).  Dropping
 // P's test therefore never changes which leaves are reached, nor what is culled by the best hit.  An
 // intermediate node whose box does NOT contain both of its children's boxes (possible only in a tree
-// handed over by a foreign builder) is kept as a node of its own and never dropped.
+// handed over by a foreign builder) is kept as a node of its own and never dropped.  Among the collapses that
+// respect this, the one with the fewest expected wide-node visits is taken (dynamic programme below).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -55,47 +56,98 @@ inline void children(const trt_bvh_node& n, Entry out[2])
 }  // namespace wide_detail
 
 // `nodes` must have passed validateBvh (every inner node reachable exactly once, indices in range).
+// Which intermediate nodes to drop is chosen by dynamic programming over the binary tree so that the expected
+// number of wide-node visits (sum of the half-areas of the boxes of all wide nodes) is minimal:
+//   root(n)    = area(n) + min_{i=1..3} best(left, i) + best(right, 4 - i)      n becomes a wide node
+//   best(n, k) = min(root(n), min_{i<k} best(left, i) + best(right, k - i))     n's subtree as <= k children of a wide node
+//   best(leaf, k) = 0
 inline WideTree collapseBvh(const trt_bvh_node* nodes, uint32_t n_nodes)
 {
     using namespace wide_detail;
     WideTree w;
     if (n_nodes == 0) return w;
-    w.nodes.reserve(n_nodes / 2 + 1);
-    struct Job { uint32_t bvh2, wide; };
+    // boxes of the inner nodes (union of the two stored child boxes) and whether a node may be opened
+    std::vector<float> area(n_nodes, 0.0f);
+    std::vector<uint8_t> openable(n_nodes, 1);   // as a child: its stored box contains its children's boxes
+    std::vector<uint32_t> order;                 // pre-order
+    order.reserve(n_nodes);
+    {
+        std::vector<uint32_t> st{0u};
+        while (!st.empty()) {
+            const uint32_t n = st.back(); st.pop_back();
+            order.push_back(n);
+            Entry c[2];
+            children(nodes[n], c);
+            for (int k = 0; k < 2; ++k) {
+                if (c[k].ref & TRT_LEAF_BIT) continue;
+                Entry g[2];
+                children(nodes[c[k].ref], g);
+                area[c[k].ref] = halfArea(c[k].b);
+                openable[c[k].ref] = contains(c[k].b, g[0].b) && contains(c[k].b, g[1].b);
+                st.push_back(c[k].ref);
+            }
+        }
+        Entry c[2];
+        children(nodes[0], c);
+        Box rb;
+        for (int a = 0; a < 3; ++a) { rb.lo[a] = std::fmin(c[0].b.lo[a], c[1].b.lo[a]); rb.hi[a] = std::fmax(c[0].b.hi[a], c[1].b.hi[a]); }
+        area[0] = halfArea(rb);
+    }
+    // bottom-up
+    std::vector<float> rootc(n_nodes, 0.0f);
+    std::vector<float> best((size_t)n_nodes * 3, 0.0f);  // best[n*3 + (k-1)], k = 1..3
+    std::vector<uint8_t> split_root(n_nodes, 1);         // i of the best (i, 4-i) split when n is a wide node
+    std::vector<uint8_t> split_k((size_t)n_nodes * 3, 0);  // 0: keep n as one child; else i of the (i, k-i) split
+    auto bestOf = [&](uint32_t ref, int k) -> float { return (ref & TRT_LEAF_BIT) ? 0.0f : best[(size_t)ref * 3 + (k - 1)]; };
+    for (size_t idx = order.size(); idx-- > 0;) {
+        const uint32_t n = order[idx];
+        const uint32_t l = nodes[n].child0, r = nodes[n].child1;
+        float br = 3.0e38f; int bi = 1;
+        for (int i = 1; i <= 3; ++i) { const float c = bestOf(l, i) + bestOf(r, 4 - i); if (c < br) { br = c; bi = i; } }
+        rootc[n] = area[n] + br;
+        split_root[n] = (uint8_t)bi;
+        for (int k = 1; k <= 3; ++k) {
+            float b = rootc[n]; int s = 0;
+            if (openable[n])
+                for (int i = 1; i < k; ++i) { const float c = bestOf(l, i) + bestOf(r, k - i); if (c < b) { b = c; s = i; } }
+            best[(size_t)n * 3 + (k - 1)] = b;
+            split_k[(size_t)n * 3 + (k - 1)] = (uint8_t)s;
+        }
+    }
+    // top-down: emit the wide nodes
+    struct Job { uint32_t bvh2, wide; uint32_t need; };
     std::vector<Job> jobs;
-    std::vector<uint32_t> parent_need;  // per wide node: sum(children-1) over the path from the root to it, inclusive
+    w.nodes.reserve(n_nodes / 2 + 1);
     w.nodes.emplace_back();
-    parent_need.push_back(0);
-    jobs.push_back({0u, 0u});
+    jobs.push_back({0u, 0u, 0u});
     const float qnan = std::numeric_limits<float>::quiet_NaN();
     while (!jobs.empty()) {
         const Job j = jobs.back();
         jobs.pop_back();
         Entry e[TRT_WIDE];
-        int n = 2;
-        children(nodes[j.bvh2], e);
-        while (n < TRT_WIDE) {
-            // open the inner child with the largest box whose own box contains both of its children's
-            int pick = -1;
-            float best = -1.0f;
-            for (int k = 0; k < n; ++k) {
-                if (e[k].ref & TRT_LEAF_BIT) continue;
-                Entry c[2];
-                children(nodes[e[k].ref], c);
-                if (!contains(e[k].b, c[0].b) || !contains(e[k].b, c[1].b)) continue;
-                const float a = halfArea(e[k].b);
-                if (a > best || pick < 0) { best = a; pick = k; }
-            }
-            if (pick < 0) break;
+        int n = 0;
+        // expand (ref, box, k): the subtree as at most k children, left to right
+        struct Item { Entry en; int k; };
+        std::vector<Item> stack;
+        {
             Entry c[2];
-            children(nodes[e[pick].ref], c);
-            for (int k = n; k > pick + 1; --k) e[k] = e[k - 1];  // keep the left-to-right (leaf index) order
-            e[pick] = c[0];
-            e[pick + 1] = c[1];
-            ++n;
+            children(nodes[j.bvh2], c);
+            const int i = split_root[j.bvh2];
+            stack.push_back({c[1], 4 - i});
+            stack.push_back({c[0], i});
+        }
+        while (!stack.empty()) {
+            const Item it = stack.back(); stack.pop_back();
+            const uint32_t ref = it.en.ref;
+            const int s = (ref & TRT_LEAF_BIT) ? 0 : split_k[(size_t)ref * 3 + (it.k - 1)];
+            if (s == 0) { e[n++] = it.en; continue; }
+            Entry c[2];
+            children(nodes[ref], c);
+            stack.push_back({c[1], it.k - s});
+            stack.push_back({c[0], s});
             ++w.dropped;
         }
-        const uint32_t need = parent_need[j.wide] + (uint32_t)(n - 1);
+        const uint32_t need = j.need + (uint32_t)(n - 1);
         if (need > w.stack_need) w.stack_need = need;
         WideNode wn;
         for (int k = 0; k < TRT_WIDE; ++k) {
@@ -108,8 +160,7 @@ inline WideTree collapseBvh(const trt_bvh_node* nodes, uint32_t n_nodes)
                 } else {
                     ref = (uint32_t)w.nodes.size();
                     w.nodes.emplace_back();
-                    parent_need.push_back(need);
-                    jobs.push_back({e[k].ref, ref});
+                    jobs.push_back({e[k].ref, ref, need});
                 }
             } else {
                 for (int a = 0; a < 6; ++a) q[a * 4 + k] = qnan;  // an all-NaN box fails every slab test
