@@ -52,7 +52,9 @@ extern "C" {
  * parent so one 64-B fetch decides both descents (bvh.cpp:156-166).
  * child refs: bit31 = 0 -> index of an inner node;
  *             bit31 = 1 -> leaf: bits 30..27 = triangle count (0..15),
- *                                bits 26..0  = first triangle (post-BVH order). */
+ *                                bits 26..0  = first triangle (post-BVH order).
+ * Post-BVH order (what bvh.cpp's in-place sort leaves behind): every triangle under child0 has a lower index than
+ * every triangle under child1; trt_create checks it (the tie rule of bvh.cpp:168-172 is applied by index). */
 typedef struct trt_bvh_node {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];

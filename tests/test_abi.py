@@ -79,3 +79,28 @@ def test_missing_hip_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_abi, "LIB_DIR", str(tmp_path))
     with pytest.raises(RuntimeError, match="only compute path"):
         _abi.load_hip()
+
+
+def test_trt_create_validates_the_bvh_before_touching_a_device():
+    """validateBvh runs on the host first: a foreign tree with a bad index, a cycle, or siblings out of post-BVH order is
+    refused with TRT_EINVAL and a message — also on a machine without a GPU."""
+    import tinyraytracing_amd as T
+    from tinyraytracing_amd._abi import BvhNode, SceneFlat
+    lib = _abi.load_hip()
+    s = T.Scene.named("veach-mis", 32, 18)
+    f = s.flat.contents
+    g = SceneFlat()
+    C.memmove(C.byref(g), C.byref(f), C.sizeof(SceneFlat))
+    nodes = (BvhNode * f.n_nodes)()
+    g.nodes = nodes
+    h = C.c_void_p()
+    for what, needle in (("index", b"out of range"), ("cycle", b"twice"), ("order", b"post-BVH order")):
+        C.memmove(nodes, f.nodes, C.sizeof(BvhNode) * f.n_nodes)
+        if what == "index":
+            nodes[3].child1 = 0x7FFFFFF0
+        elif what == "cycle":
+            nodes[5].child0 = 0
+        else:
+            nodes[0].child0, nodes[0].child1 = f.nodes[0].child1, f.nodes[0].child0
+        assert lib.trt_create(C.byref(g), 0, C.byref(h)) == 1
+        assert needle in lib.trt_last_error(), (what, lib.trt_last_error())

@@ -362,6 +362,9 @@ def test_error_codes(renderer_factory):
     assert lib.trt_create(C.byref(g), 0, C.byref(h)) == 1 and b"bvh" in lib.trt_last_error()
     nodes[0].child0 = 0                                          # a cycle
     assert lib.trt_create(C.byref(g), 0, C.byref(h)) == 1
+    C.memmove(nodes, f.nodes, C.sizeof(BvhNode) * f.n_nodes)     # siblings swapped: child0's triangles no longer come first
+    nodes[0].child0, nodes[0].child1 = f.nodes[0].child1, f.nodes[0].child0
+    assert lib.trt_create(C.byref(g), 0, C.byref(h)) == 1 and b"post-BVH order" in lib.trt_last_error()
 
 
 def test_smoke_entry():

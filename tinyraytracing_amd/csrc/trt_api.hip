@@ -113,7 +113,11 @@ int upload(trt_handle* h, const T* src, size_t count, const T** dst)
 
 // Structural check of the flat BVH and its true depth (the kernels size their
 // stacks from it): every child reference in range, every leaf range in range,
-// no node reachable twice (no cycles / DAGs).
+// no node reachable twice (no cycles / DAGs), and every triangle under child0 has
+// a lower index than every triangle under child1 — the post-BVH order of the
+// reference (bvh.cpp sorts the triangle array in place and recurses on its two halves),
+// which is what lets the between-leaves tie rule "r1 if r1 emissive else r2" (bvh.cpp:168-172)
+// be applied by triangle index in any visiting order.
 int validateBvh(const trt_scene* s, uint32_t* depth_out)
 {
     std::vector<uint8_t> seen(s->n_nodes, 0);
@@ -141,6 +145,42 @@ int validateBvh(const trt_scene* s, uint32_t* depth_out)
             } else {
                 stack.emplace_back(c, dep + 1);
             }
+        }
+    }
+    {   // index order of siblings: (min, max) triangle index under every inner node, children before parents
+        std::vector<uint32_t> order;
+        order.reserve(s->n_nodes);
+        std::vector<uint32_t> st{0u};
+        while (!st.empty()) {
+            const uint32_t n = st.back();
+            st.pop_back();
+            order.push_back(n);
+            if (!(s->nodes[n].child0 & TRT_LEAF_BIT)) st.push_back(s->nodes[n].child0);
+            if (!(s->nodes[n].child1 & TRT_LEAF_BIT)) st.push_back(s->nodes[n].child1);
+        }
+        std::vector<uint32_t> lo(s->n_nodes, 0xFFFFFFFFu), hi(s->n_nodes, 0u);
+        std::vector<uint8_t> has(s->n_nodes, 0);
+        for (size_t k = order.size(); k-- > 0;) {
+            const uint32_t n = order[k];
+            uint32_t clo[2], chi[2];
+            bool chas[2];
+            const uint32_t ch[2] = {s->nodes[n].child0, s->nodes[n].child1};
+            for (int c = 0; c < 2; ++c) {
+                if (ch[c] & TRT_LEAF_BIT) {
+                    const uint32_t first = TRT_LEAF_FIRST(ch[c]), count = TRT_LEAF_COUNT(ch[c]);
+                    chas[c] = count != 0;
+                    clo[c] = first;
+                    chi[c] = first + count - (count ? 1u : 0u);
+                } else {
+                    chas[c] = has[ch[c]] != 0;
+                    clo[c] = lo[ch[c]];
+                    chi[c] = hi[ch[c]];
+                }
+            }
+            if (chas[0] && chas[1] && !(chi[0] < clo[1])) return fail(TRT_EINVAL, "bvh: triangles under child0 must precede those under child1 (post-BVH order)");
+            has[n] = chas[0] || chas[1];
+            lo[n] = std::min(chas[0] ? clo[0] : 0xFFFFFFFFu, chas[1] ? clo[1] : 0xFFFFFFFFu);
+            hi[n] = std::max(chas[0] ? chi[0] : 0u, chas[1] ? chi[1] : 0u);
         }
     }
     *depth_out = max_depth;
