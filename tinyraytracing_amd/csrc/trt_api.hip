@@ -392,7 +392,9 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     }
     if (int e = upload(h.get(), s->nodes, (size_t)s->n_nodes, &h->sc.nodes)) return e;
     {   // the 4-wide collapse every per-lane traversal walks; its stack bound sizes the LDS stack / the spill area
-        const WideTree wide = collapseBvh(s->nodes, s->n_nodes);
+        bool greedy = s->n_tris > 4000000u;  // measured: trt_wide.h
+        if (const char* e = std::getenv("TRT_WIDE_GREEDY")) greedy = std::atoi(e) != 0;
+        const WideTree wide = greedy ? collapseBvhGreedy(s->nodes, s->n_nodes) : collapseBvh(s->nodes, s->n_nodes);
         if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
         h->sc.n_wnodes = (uint32_t)wide.nodes.size();
         h->depth = wide.stack_need + 1;
