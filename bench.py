@@ -78,12 +78,20 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # TRT_BENCH_BACKEND=gloo: rehearsal of the multi-rank logic on a box with fewer GPUs than ranks (ranks share
+    # device local_rank % device_count, the gather goes through host memory); the real run is nccl = RCCL over xGMI.
+    backend = os.environ.get("TRT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     seed = a.seed if a.seed is not None else {"back": T.SEED_BACK, "veach-mis": 0x5EED0002, "staircase": T.SEED_STAIRCASE,
                                                "soup": T.SEED_SOUP, "blob": T.SEED_BLOB}[a.scene]
@@ -150,10 +158,11 @@ def main():
         t_ov = time.perf_counter() - t_ov
         overlap_extra = {"value": round(rays_ov / t_ov / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(t_ov / a.steps * 1e3, 3)}
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        red_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        rr = torch.tensor([rays_rank], dtype=torch.int64, device=f"cuda:{local_rank}")
+        rr = torch.tensor([rays_rank], dtype=torch.int64, device=red_dev)
         dist.all_reduce(rr)
         rays_total = int(rr.item())
     else:

@@ -83,11 +83,13 @@ def render_distributed(render_fn, width, height, spp, seed, dist=None, device=No
     else:
         buf = torch.zeros((pad_rows, width, 3), dtype=torch.float32, device=t.device)
         buf[:nrows] = t.reshape(nrows, width, 3)
+    if buf.is_cuda and dist.get_backend() != "nccl":
+        buf = buf.cpu()  # gloo gathers host tensors (tests, rehearsals); RCCL gathers device to device over xGMI
     gather_list = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, gather_list, dst=0)  # the single collective of the data path
     if rank != 0:
         return None, stats
-    img = torch.empty((height, width, 3), dtype=torch.float32, device=t.device)
-    for r, idx in enumerate(_row_indices(width, height, world, row_block, t.device)):
+    img = torch.empty((height, width, 3), dtype=torch.float32, device=buf.device)
+    for r, idx in enumerate(_row_indices(width, height, world, row_block, buf.device)):
         img.index_copy_(0, idx, gather_list[r][: idx.numel()])
     return img, stats
