@@ -32,6 +32,18 @@ typedef struct oracle_stats {
 int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats,
                   int threads, int mode);
 
+/* ORACLE_MODE_LITERAL: the reference's own arithmetic (oracle_literal.cpp): plane + edge-cross triangle test with the
+ * stored unit normal (bvh.cpp:177-209), double least-squares barycentrics (triangle.cpp:12-29), double scalars and libm
+ * where the reference has them, shade() as a recursion; same counter RNG and draw order as the modes above.  Parity
+ * mode only (max_depth 0, no TRT_FLAG_FIXED_*).  Used to measure and freeze the stated tolerance between the
+ * reference's formulation and the one the HIP kernels share with oracle_render(). */
+int oracle_render_literal(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats, int threads);
+/* interactTriangle + findBaryCor literally on one triangle: returns 1 on hit, out = {t, b0, b1, b2}. */
+int oracle_tri_test_literal(const float v[9], const float o[3], const float d[3], float out[4]);
+/* traverseBVH with the literal triangle test on a ray batch (uv = barycentric weights of v1, v2 from findBaryCor). */
+int oracle_trace_literal(const trt_scene* scene, uint64_t n, const float* org, const float* dir,
+                         float* t, int32_t* tri, float* uv);
+
 #define ORACLE_TRACE_REFERENCE 0 /* recursive, both children, no culling (bvh.cpp:146-175) */
 #define ORACLE_TRACE_BRUTE 1     /* every triangle in index order through the leaf rule */
 int oracle_trace(const trt_scene* scene, uint64_t n, const float* org, const float* dir,

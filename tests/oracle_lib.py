@@ -53,6 +53,9 @@ def lib():
     L.oracle_prims_pow01.argtypes = [C.c_float, C.c_float]
     L.oracle_prims_uniform.restype = C.c_float
     L.oracle_prims_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.oracle_render_literal.argtypes = [C.POINTER(SceneFlat), C.POINTER(Params), fp, C.POINTER(OracleStats), C.c_int]
+    L.oracle_tri_test_literal.argtypes = [fp, fp, fp, fp]
+    L.oracle_trace_literal.argtypes = [C.POINTER(SceneFlat), C.c_uint64, fp, fp, fp, C.POINTER(C.c_int32), fp]
     L.oracle_debug_path.argtypes = [C.POINTER(SceneFlat), C.POINTER(Params), C.c_int, C.c_int, C.c_int, fp, C.c_int]
     _lib = L
     return L
@@ -72,6 +75,41 @@ def render(flat, params, threads=0, mode=MODE_ITERATIVE):
     if rc != 0:
         raise RuntimeError(f"oracle_render failed: {rc}")
     return out, st
+
+
+def render_literal(flat, params, threads=0):
+    """ORACLE_MODE_LITERAL: the reference's own arithmetic (oracle/oracle_literal.cpp)."""
+    nrows = len(_rows(params))
+    tw = params.x1 - params.x0
+    out = np.empty((nrows, tw, 3), np.float32)
+    st = OracleStats()
+    rc = lib().oracle_render_literal(flat, C.byref(params), out.ctypes.data_as(fp), C.byref(st), threads)
+    if rc != 0:
+        raise RuntimeError(f"oracle_render_literal failed: {rc}")
+    return out, st
+
+
+def trace_literal(flat, org, direction):
+    org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+    direction = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+    n = org.shape[0]
+    t = np.empty(n, np.float32)
+    tri = np.empty(n, np.int32)
+    uv = np.empty((n, 2), np.float32)
+    rc = lib().oracle_trace_literal(flat, n, org.ctypes.data_as(fp), direction.ctypes.data_as(fp), t.ctypes.data_as(fp),
+                                    tri.ctypes.data_as(C.POINTER(C.c_int32)), uv.ctypes.data_as(fp))
+    if rc != 0:
+        raise RuntimeError(f"oracle_trace_literal failed: {rc}")
+    return t, tri, uv
+
+
+def tri_test_literal(v, o, d):
+    va, vp = _f3(v)
+    oa, op = _f3(o)
+    da, dp = _f3(d)
+    out = np.zeros(4, np.float32)
+    hit = lib().oracle_tri_test_literal(vp, op, dp, out.ctypes.data_as(fp))
+    return bool(hit), out
 
 
 def _rows(p):
