@@ -13,6 +13,7 @@
 using namespace trtd;
 
 namespace {
+int g_node_kind = 1;  // hostsim_set_node_kind
 struct ArrayStack {
     uint32_t s[1024];
     void push(int sp, uint32_t v) { s[sp] = v; }
@@ -29,6 +30,8 @@ struct HostScene {
     std::vector<LightDev> lights;
     std::vector<LightTriDev> ltris;
     WideTree wide;
+    CompressedTree comp;
+    int nk = 0;  // node kind the traversal walks: 0 exact wide nodes, 1 compressed (trt_create's default when the tree allows it)
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
     {
@@ -59,6 +62,10 @@ struct HostScene {
         wide = collapseBvh(s->nodes, s->n_nodes);
         sc.wnodes = wide.nodes.data();
         sc.n_wnodes = (uint32_t)wide.nodes.size();
+        comp = compressWide(wide, s->nodes, s->n_nodes, s->n_tris);
+        sc.cnodes = comp.ok ? comp.nodes.data() : nullptr;
+        sc.leaf_box = comp.ok ? comp.leaf_box.data() : nullptr;
+        nk = (comp.ok && g_node_kind != 0) ? 1 : 0;
         sc.tri_isect = isect.data();
         sc.tri_shade = shade.data();
         sc.materials = mats.data();
@@ -83,6 +90,20 @@ struct HostScene {
     }
 };
 }  // namespace
+
+// 0: exact wide nodes; 1 (default): compressed nodes where the tree allows them.  Returns the previous setting.
+extern "C" int hostsim_set_node_kind(int nk)
+{
+    const int old = g_node_kind;
+    g_node_kind = nk;
+    return old;
+}
+// 1 when `s` can be walked with compressed nodes (nested, finite boxes)
+extern "C" int hostsim_compressible(const trt_scene* s)
+{
+    const WideTree w = collapseBvh(s->nodes, s->n_nodes);
+    return compressWide(w, s->nodes, s->n_nodes, s->n_tris).ok ? 1 : 0;
+}
 
 extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* out_rgb, uint64_t rays[3])
 {
@@ -121,7 +142,8 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
             r_cam++;
             for (;;) {
                 // k_trace_closest
-                const Hit h = traceClosest<ArrayStack, false>(hs.sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni, nt);
+                const Hit h = hs.nk ? traceClosest<ArrayStack, false, 1>(hs.sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni, nt)
+                                    : traceClosest<ArrayStack, false, 0>(hs.sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni, nt);
                 const f4 hit4 = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
                 // k_shade
                 ShadeCtx cx;
@@ -135,7 +157,8 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
                     const f3 w = cx.beta * contrib;
                     r_sh++;
                     // k_trace_shadow
-                    const Hit sh = traceClosest<ArrayStack, false>(hs.sc, cx.vx.P, wo, stk, ni, nt, t_max, fixed, !fixed);
+                    const Hit sh = hs.nk ? traceClosest<ArrayStack, false, 1>(hs.sc, cx.vx.P, wo, stk, ni, nt, t_max, fixed, !fixed)
+                                         : traceClosest<ArrayStack, false, 0>(hs.sc, cx.vx.P, wo, stk, ni, nt, t_max, fixed, !fixed);
                     if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)hs.sc.lights[li].mat)) L = L + w;
                 }
                 f4 nra, nrb, nbt;
@@ -166,7 +189,8 @@ extern "C" int hostsim_trace(const trt_scene* s, uint64_t n, const float* org, c
     for (long long i = 0; i < (long long)n; ++i) {
         ArrayStack stk;
         uint32_t ni = 0, nt = 0;
-        const Hit h = traceClosest<ArrayStack, true>(hs.sc, ld3(org + i * 3), ld3(dir + i * 3), stk, ni, nt);
+        const Hit h = hs.nk ? traceClosest<ArrayStack, true, 1>(hs.sc, ld3(org + i * 3), ld3(dir + i * 3), stk, ni, nt)
+                            : traceClosest<ArrayStack, true, 0>(hs.sc, ld3(org + i * 3), ld3(dir + i * 3), stk, ni, nt);
         t[i] = h.t;
         tri[i] = h.tri;
         if (uv) { uv[i * 2] = h.u; uv[i * 2 + 1] = h.v; }

@@ -18,8 +18,19 @@ def lib():
         L = C.CDLL(SO)
         L.hostsim_render.argtypes = [C.POINTER(SceneFlat), C.POINTER(Params), fp, C.POINTER(C.c_uint64)]
         L.hostsim_trace.argtypes = [C.POINTER(SceneFlat), C.c_uint64, fp, fp, fp, C.POINTER(C.c_int32), fp, C.POINTER(C.c_uint64)]
+        L.hostsim_set_node_kind.argtypes = [C.c_int]
+        L.hostsim_compressible.argtypes = [C.POINTER(SceneFlat)]
         _lib = L
     return _lib
+
+
+def set_node_kind(nk):
+    """0 = exact 4-wide nodes, 1 = compressed nodes (the default wherever the tree is nested); returns the old setting."""
+    return lib().hostsim_set_node_kind(int(nk))
+
+
+def compressible(flat):
+    return bool(lib().hostsim_compressible(flat))
 
 
 def render(flat, p):

@@ -236,8 +236,9 @@ def test_config2_stripes_union(renderer_factory):
 
 
 def test_config3_soup_tile_vs_oracle(renderer_factory):
-    """Config 3 (deep-BVH stress) at reduced triangle count for the CPU checker: 1920x1080, 64 spp."""
-    s = get_scene("soup", 1920, 1080, n=300000)
+    """Config 3 (deep-BVH stress) at its stated size — 1 M random triangles, 1920x1080, 64 spp: tiles against the oracle."""
+    s = get_scene("soup", 1920, 1080, n=1_000_000)
+    assert s.info["n_triangles"] >= 1_000_000
     r = renderer_factory(s)
     for (x0, y0) in ((960, 540), (100, 1000)):
         pt = T.make_params(1920, 1080, 64, T.SEED_SOUP, tile=(x0, y0, x0 + 16, y0 + 8))
@@ -261,6 +262,12 @@ def test_config5_ten_million_triangles_at_4k_tile_vs_oracle():
             ref, ost = O.render(s.flat, pt)
             assert_same_image(img, ref, f"blob-10M tile {x0},{y0}")
             assert st.rays == ost.rays
+        # the stated sample count: 4096 spp (sample indices >= 1024, the L / 4096.0f scaling) on a 4 x 4 tile
+        pt = T.make_params(3840, 2160, 4096, T.SEED_BLOB, tile=(1930, 1100, 1934, 1104))
+        img, st = r.render(pt)
+        ref, ost = O.render(s.flat, pt)
+        assert_same_image(img, ref, "blob-10M 4x4 tile at 4096 spp")
+        assert st.rays == ost.rays and st.rays_camera == 16 * 4096
         full = T.make_params(3840, 2160, 2, T.SEED_BLOB)
         a, sa = r.render(full)
         b, sb = r.render(full)
@@ -286,6 +293,53 @@ def test_config4_staircase_tile_at_1024spp_vs_oracle(renderer_factory):
 
 
 # ------------------------------------------------------------------ edge cases and error behaviour
+def test_tiny_tree_with_children_before_parents(scene_factory):
+    """the wave-uniform walk of tiny trees evaluates nodes in index order, which is only right when every
+    inner child follows its parent.  A caller's tree that does not (here: `back` with its nodes renumbered in reverse)
+    must still give the oracle's hits and image — trt_create walks it per lane instead."""
+    s = T.Scene.named("back", 64, 64)
+    assert SU.renumber_nodes_reversed(s) > 0
+    r = T.Renderer(s, 0)
+    try:
+        lo, hi = raygen.scene_bounds(s)
+        org, dirs = raygen.random_rays(50000, lo - 5, hi + 5, seed=5)
+        t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+        t1, tri1, uv1 = r.trace_closest(org, dirs)
+        assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+        p = T.make_params(64, 64, 16, T.SEED_BACK)
+        img, st = r.render(p)
+        ref, ost = O.render(s.flat, p)
+        assert_same_image(img, ref, "back with reversed node order")
+        assert st.rays == ost.rays
+    finally:
+        r.close()
+        s.close()
+
+
+def test_failure_mid_render_leaves_the_handle_usable(monkeypatch):
+    """an error return with kernels in flight (here an injected one, after bounce 1 has been issued on
+    both overlapped passes) must drain the streams; the same handle then renders the oracle's image."""
+    s = get_scene("veach-mis", 96, 54)
+    monkeypatch.setenv("TRT_TEST_FAIL_AT_BOUNCE", "1")
+    r = T.Renderer(s, 0)
+    monkeypatch.delenv("TRT_TEST_FAIL_AT_BOUNCE")
+    p = T.make_params(96, 54, 8, 0x5EED0002, flags=T.TRT_FLAG_OVERLAP)
+    try:
+        with pytest.raises(T.TrtError, match="injected failure"):
+            r.render(p)
+        for _ in range(2):
+            img, st = r.render(p)
+            ref, ost = O.render(s.flat, p)
+            assert_same_image(img, ref, "render after a failed call")
+            assert st.rays == ost.rays
+        tiny = T.make_params(96, 54, 8, 0x5EED0002, flags=T.TRT_FLAG_OVERLAP, mem_budget=1024)
+        with pytest.raises(T.TrtError, match="mem_budget too small"):
+            r.render(tiny)
+        assert_same_image(r.render(p)[0], ref, "render after TRT_ENOMEM")
+    finally:
+        r.close()
+
+
 def test_empty_and_single_triangle_scenes(tmp_path):
     SU.write_scene(tmp_path, "empty", "v 0 0 0\n", SU.MTL_BASIC, w=16, h=16)
     s = SU.load(tmp_path, "empty")

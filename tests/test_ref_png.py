@@ -22,8 +22,8 @@ Which snapshot belongs to the committed code was established by ranking all of t
                           ceiling (indirect light only) most: older revisions of the indirect term.  They pin Q1/Q2 and the
                           geometry, not the brightness.
 
-Tolerances are stated per fixture below; the CPU tests use the oracle at a few spp, the -m gpu tests the HIP render at
-64 spp through the C-ABI.
+Tolerances are stated per fixture below; the CPU tests use the oracle at a few spp, the -m gpu tests the HIP render
+through the C-ABI at the snapshot's own sample count.
 """
 import os
 
@@ -128,21 +128,33 @@ def test_back_snapshots_pin_pixel_grid_and_geometry(fixture):
 
 
 # ------------------------------------------------------------------------------------------------ HIP path
+# fixture -> (samples per pixel of the snapshot = what the HIP render uses, max median block error, max p90, min correlation)
+GPU_BOUNDS = {
+    "veach-mis_image10.png": (10, 0.02, 0.07, 0.998),      # measured 0.0105, 0.045, 0.9994
+    "staircase_image10.png": (10, 0.075, 0.25, 0.975),     # measured 0.056, 0.194, 0.985 (two 10-spp renders of a high-variance scene)
+    "staircase_image256.png": (256, 0.10, 0.25, 0.97),
+}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture", sorted(MATCHING))
 def test_gpu_render_matches_the_references_own_snapshot(fixture, renderer_factory):
-    """The HIP render through the C-ABI at the snapshot's native resolution, 64 spp (less noise than the CPU test: tighter)."""
+    """The HIP render through the C-ABI at the snapshot's native resolution AND sample count (the 8-bit encode clamps at 1
+    after averaging: a 10-spp image loses more of its fireflies to the clamp than a converged one, so like is compared
+    with like)."""
     scene_name = MATCHING[fixture][0]
+    spp, max_med, max_p90, min_corr = GPU_BOUNDS[fixture]
     png = _png(fixture)
     h, w = png.shape[:2]
     s = get_scene(scene_name, w, h)
     r = renderer_factory(s)
-    img, _ = r.render(T.make_params(w, h, 64, SEEDS[scene_name]))
+    img, _ = r.render(T.make_params(w, h, spp, SEEDS[scene_name]))
     med, p90, corr = _compare(img, png)
-    bound = {"veach-mis_image10.png": (0.025, 0.08, 0.998), "staircase_image10.png": (0.09, 0.22, 0.97), "staircase_image256.png": (0.10, 0.22, 0.97)}[fixture]
-    assert med <= bound[0] and p90 <= bound[1] and corr >= bound[2], (med, p90, corr)
-    fixed, _ = r.render(T.make_params(w, h, 64, SEEDS[scene_name], flags=T.TRT_FLAG_FIXED_NEE))
+    print(f"{fixture}: HIP {spp} spp vs snapshot: median block error {med:.4f}, p90 {p90:.4f}, correlation {corr:.4f}")
+    assert med <= max_med and p90 <= max_p90 and corr >= min_corr, (med, p90, corr)
+    fixed, _ = r.render(T.make_params(w, h, spp, SEEDS[scene_name], flags=T.TRT_FLAG_FIXED_NEE))
     med_fixed, _, _ = _compare(fixed, png)
+    print(f"{fixture}: with TRT_FLAG_FIXED_NEE: median block error {med_fixed:.4f}")
     assert med_fixed >= 0.15 and med_fixed >= 2.0 * med, (med, med_fixed)
 
 

@@ -76,12 +76,33 @@ struct trt_handle {
     uint32_t bvh2_depth = 0;  // depth of the caller's BVH2
     uint32_t lds_tab[4] = {0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles that k_shade stages in LDS
     int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
+    int node_kind = 0;        // what the per-lane traversal walks: 0 exact 128-B wide nodes, 1 compressed 64-B nodes (trt_path.h CNode)
+    // Grid of the traversal kernels for a queue of n rays.  A persistent wave refills finished lanes from its own slice
+    // of the queue, which only pays when the slice holds several batches: aim for rays_per_wave rays per wave, but do
+    // not go below the fill_blocks that fill the chip's wave slots, nor above one block per 256 rays.
+    // (TRT_TRACE_RPW / TRT_TRACE_FILLB / TRT_TRACE_MAXB in the environment at trt_create: tuning.)  Per handle: no
+    // process-wide mutable state in this library.
+    uint32_t rays_per_wave = 256, fill_blocks = 2048, max_blocks = 8192;
+    uint32_t traceGrid(uint32_t n) const
+    {
+        uint32_t b = (n + TRT_TRACE_BLOCK - 1) / TRT_TRACE_BLOCK;
+        if (rays_per_wave > 64) {
+            const uint32_t want = (uint32_t)(((uint64_t)n + 4ull * rays_per_wave - 1) / (4ull * rays_per_wave));
+            b = std::min(b, std::max(fill_blocks, want));
+        }
+        b = std::min(std::max(b, 8u), std::min(max_blocks, 8192u));
+        return (b + 7u) & ~7u;  // multiple of 8 for the XCD swizzle; <= MAX_TRACE_BLOCKS (8192) since that is one too
+    }
     uint32_t tail_n = 131072;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
     DevBuf arena, spill, small_buf, out_buf, io_buf;
     size_t spill_words_per_slot = 0;
     hipStream_t slot_streams[2] = {nullptr, nullptr};  // one per concurrent pass (trt_render_device)
     int n_slots = 2;                                   // TRT_SLOTS=1 in the environment vetoes TRT_FLAG_OVERLAP
     uint32_t* pinned_counts = nullptr;                 // host-pinned landing zone of the per-bounce queue lengths
+    uint32_t slot_seq[2] = {0, 0};                     // last sequence number published per slot: monotonic over the handle's life, so a
+                                                       // word left behind by an earlier (even a failed) call never equals an expected one
+    int fail_at_bounce = -1;                           // TRT_TEST_FAIL_AT_BOUNCE at trt_create: the next render reports an injected failure
+                                                       // after issuing that bounce (exercises the error path; consumed once)
     std::vector<hipEvent_t> events;
     ~trt_handle()
     {
@@ -201,28 +222,12 @@ int checkParams(const trt_handle* h, const trt_params* p)
 
 bool rowSelected(const trt_params* p, int y) { return p->row_mod <= 1 || ((y / p->row_block) % p->row_mod) == p->row_rem; }
 
-// Grid of the traversal kernels for a queue of n rays.  A persistent wave refills finished lanes from its own slice
-// of the queue, which only pays when the slice holds several batches: aim for g_rays_per_wave rays per wave, but do
-// not go below the g_fill_blocks that fill the chip's wave slots, nor above one block per 256 rays.
-// (TRT_TRACE_RPW / TRT_TRACE_FILLB / TRT_TRACE_MAXB in the environment: tuning.)
-uint32_t g_rays_per_wave = 256, g_fill_blocks = 2048, g_max_blocks = MAX_TRACE_BLOCKS;
 uint32_t tailGrid(uint32_t n)
 {
     uint32_t b = (n + TRT_TRACE_BLOCK - 1) / TRT_TRACE_BLOCK;
     b = std::min(std::max(b, 8u), MAX_TRACE_BLOCKS);
     return (b + 7u) & ~7u;
 }
-uint32_t traceGrid(uint32_t n)
-{
-    uint32_t b = (n + TRT_TRACE_BLOCK - 1) / TRT_TRACE_BLOCK;
-    if (g_rays_per_wave > 64) {
-        const uint32_t want = (uint32_t)(((uint64_t)n + 4ull * g_rays_per_wave - 1) / (4ull * g_rays_per_wave));
-        b = std::min(b, std::max(g_fill_blocks, want));
-    }
-    b = std::min(std::max(b, 8u), std::min(g_max_blocks, MAX_TRACE_BLOCKS));
-    return (b + 7u) & ~7u;  // multiple of 8 for the XCD swizzle; <= MAX_TRACE_BLOCKS since that is one too
-}
-
 // Traversal kernels: the LDS stack holds 8 or 16 levels without spill code when the scene's verified BVH
 // depth fits, else 16 levels + a global spill area (16 KiB per block keeps 8 waves per SIMD resident);
 // the wave driver (trt_kernels.h) is the static one for shallow trees, the scheduler one otherwise.
@@ -266,48 +271,40 @@ struct Timer {
     }
 };
 
+// One kernel per (driver, LDS depth, node kind); the scene picks the combination once, in trt_create.
+#define TRT_LAUNCH_CLOSEST(DEPTH, SPILL, IMPL, NK) \
+    hipLaunchKernelGGL((k_trace_closest<COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats)
+#define TRT_LAUNCH_SHADOW(DEPTH, SPILL, IMPL, NK) \
+    hipLaunchKernelGGL((k_trace_shadow<COUNT, DEPTH, SPILL, IMPL, NK>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any)
+#define TRT_BY_DEPTH(LAUNCH, IMPL, NK)                                       \
+    do {                                                                     \
+        if (h->depth <= 8) LAUNCH(8, false, IMPL, NK);                       \
+        else if (h->depth <= 16) LAUNCH(16, false, IMPL, NK);                \
+        else LAUNCH(TRT_LDS_STACK_MAX, true, IMPL, NK);                      \
+    } while (0)
+#define TRT_BY_IMPL(LAUNCH, NK)                                              \
+    do {                                                                     \
+        if (h->trace_impl == 1) TRT_BY_DEPTH(LAUNCH, 1, NK);                 \
+        else if (h->trace_impl == 2) TRT_BY_DEPTH(LAUNCH, 2, NK);            \
+        else TRT_BY_DEPTH(LAUNCH, 3, NK);                                    \
+    } while (0)
+
 template <bool COUNT, bool PRIMARY>
 void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats)
 {
-    const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_closest<COUNT, 1, false, 0, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-    else if (h->trace_impl == 1) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 1, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 1, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 1, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-    }
-    else if (h->trace_impl == 2) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 2, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 2, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 2, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-    }
-    else if (h->trace_impl == 3) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_closest<COUNT, 8, false, 3, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_closest<COUNT, 16, false, 3, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-        else hipLaunchKernelGGL((k_trace_closest<COUNT, TRT_LDS_STACK_MAX, true, 3, PRIMARY>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats);
-    }
+    const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
+    if (h->trace_impl == 0) TRT_LAUNCH_CLOSEST(1, false, 0, 0);
+    else if (h->node_kind == 1) TRT_BY_IMPL(TRT_LAUNCH_CLOSEST, 1);
+    else TRT_BY_IMPL(TRT_LAUNCH_CLOSEST, 0);
 }
 
 template <bool COUNT>
 void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any)
 {
-    const dim3 g(traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->trace_impl == 0) hipLaunchKernelGGL((k_trace_shadow<COUNT, 1, false, 0>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-    else if (h->trace_impl == 1) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 1>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-    }
-    else if (h->trace_impl == 2) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 2>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-    }
-    else if (h->trace_impl == 3) {
-        if (h->depth <= 8) hipLaunchKernelGGL((k_trace_shadow<COUNT, 8, false, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-        else if (h->depth <= 16) hipLaunchKernelGGL((k_trace_shadow<COUNT, 16, false, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-        else hipLaunchKernelGGL((k_trace_shadow<COUNT, TRT_LDS_STACK_MAX, true, 3>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any);
-    }
+    const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
+    if (h->trace_impl == 0) TRT_LAUNCH_SHADOW(1, false, 0, 0);
+    else if (h->node_kind == 1) TRT_BY_IMPL(TRT_LAUNCH_SHADOW, 1);
+    else TRT_BY_IMPL(TRT_LAUNCH_SHADOW, 0);
 }
 
 }  // namespace
@@ -368,12 +365,19 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     h->sc.sched_lf_w = s->n_tris <= 200000u ? 1u : 3u;
     if (const char* e = std::getenv("TRT_REFILL_MIN")) h->sc.refill_min = std::min(64u, std::max(1u, (uint32_t)std::strtoul(e, nullptr, 10)));
     if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: refill_min %u tail_n %u\n", h->sc.refill_min, h->tail_n);
-    if (const char* e = std::getenv("TRT_TRACE_RPW")) g_rays_per_wave = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("TRT_TRACE_FILLB")) g_fill_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("TRT_TRACE_MAXB")) g_max_blocks = std::max(8u, (uint32_t)std::strtoul(e, nullptr, 10));
+    if (const char* e = std::getenv("TRT_TRACE_RPW")) h->rays_per_wave = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TRT_TRACE_FILLB")) h->fill_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TRT_TRACE_MAXB")) h->max_blocks = std::max(8u, (uint32_t)std::strtoul(e, nullptr, 10));
     // shallow trees (everything L1-resident, a dozen steps per ray): the static driver has the least overhead;
     // deeper ones gain more from lane refill and step scheduling (measured: DESIGN.md)
-    const bool tiny = s->n_nodes <= 32 && s->n_tris <= 64;  // the wave-uniform walk needs a 32-bit reach mask
+    // the wave-uniform walk needs a 32-bit reach mask, and it evaluates the nodes in index order: every inner child must
+    // come after its parent (all builders here emit parents first; a caller's tree that does not is walked per lane)
+    bool tiny = s->n_nodes <= 32 && s->n_tris <= 64;
+    for (uint32_t n = 0; tiny && n < s->n_nodes; ++n) {
+        const uint32_t ch[2] = {s->nodes[n].child0, s->nodes[n].child1};
+        for (uint32_t c : ch)
+            if (!(c & TRT_LEAF_BIT) && c <= n) tiny = false;
+    }
     h->trace_impl = tiny ? 0 : (depth <= 8 ? 1 : 3);
     if (const char* e = std::getenv("TRT_TRACE_IMPL")) { const int v = std::atoi(e); if (v >= (tiny ? 0 : 1) && v <= 3) h->trace_impl = v; }
 
@@ -395,9 +399,26 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         bool greedy = s->n_tris > 4000000u;  // measured: trt_wide.h
         if (const char* e = std::getenv("TRT_WIDE_GREEDY")) greedy = std::atoi(e) != 0;
         const WideTree wide = greedy ? collapseBvhGreedy(s->nodes, s->n_nodes) : collapseBvh(s->nodes, s->n_nodes);
-        if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
         h->sc.n_wnodes = (uint32_t)wide.nodes.size();
         h->depth = wide.stack_need + 1;
+        // 64-B compressed nodes + exact leaf boxes (nested trees only: every builder's is) where they measured faster: the
+        // scenes whose node array does not fit the L2s (half the lines to fetch); on L2-resident scenes the 36 extra VALU
+        // instructions of a visit cost more than the three loads they save.  TRT_NODE_KIND=0/1 forces either.
+        bool want_c = h->trace_impl != 0 && s->n_tris > 4000000u;
+        if (const char* e = std::getenv("TRT_NODE_KIND")) want_c = h->trace_impl != 0 && std::atoi(e) != 0;
+        CompressedTree comp;
+        if (want_c) comp = compressWide(wide, s->nodes, s->n_nodes, s->n_tris);
+        h->sc.wnodes = nullptr;
+        h->sc.cnodes = nullptr;
+        h->sc.leaf_box = nullptr;
+        if (comp.ok) {
+            h->node_kind = 1;
+            if (int e = upload(h.get(), comp.nodes.data(), comp.nodes.size(), &h->sc.cnodes)) return e;
+            if (int e = upload(h.get(), comp.leaf_box.data(), comp.leaf_box.size(), &h->sc.leaf_box)) return e;
+        } else {
+            if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
+        }
+        if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: %zu wide nodes, node kind %d, stack need %u\n", wide.nodes.size(), h->node_kind, wide.stack_need);
     }
     {
         std::vector<MaterialDev> mats(s->n_materials);
@@ -461,7 +482,9 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     if (int e = h->spill.ensure(h->spill_words_per_slot * 2 * sizeof(uint32_t))) return e;  // one area per concurrent pass
     for (hipStream_t& st : h->slot_streams) HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIPC(hipHostMalloc((void**)&h->pinned_counts, 2 * (2 * COUNT_ROW + 16) * sizeof(uint32_t), hipHostMallocDefault));  // per slot: counters + sequence word
+    std::memset(h->pinned_counts, 0, 2 * (2 * COUNT_ROW + 16) * sizeof(uint32_t));  // sequence words start at 0; the first one asked for is 1
     if (const char* e = std::getenv("TRT_SLOTS")) h->n_slots = std::atoi(e) >= 2 ? 2 : 1;
+    if (const char* e = std::getenv("TRT_TEST_FAIL_AT_BOUNCE")) h->fail_at_bounce = std::atoi(e);
     *out = h.release();
     return TRT_OK;
 }
@@ -581,8 +604,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         for (uint32_t l = 0; l < nl; ++l) { S.SQ[l].sa = take(); S.SQ[l].sb = take(); S.SQ[l].sw = take(); }
         S.d_counts = (uint32_t*)(sb + rows_bytes + counts_bytes * (size_t)k);
         S.host_counts = h->pinned_counts + (size_t)k * (2 * COUNT_ROW + 16);
-        S.host_counts[2 * COUNT_ROW] = 0;
-        S.seq = 0;
+        S.seq = h->slot_seq[k];
         S.spill = (uint32_t*)h->spill.p + (size_t)k * h->spill_words_per_slot;
     }
 
@@ -612,6 +634,24 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     hipEvent_t ev_begin = tm.get(0), ev_end = tm.get(1), ev_resolved = tm.get(2);
     if (!ev_begin || !ev_end || !ev_resolved) return fail(TRT_EHIP, "hipEventCreate failed");
     HIPC(hipEventRecord(ev_begin, stream));
+    // From here on work is in flight on the slot streams.  Whatever way this function is left, nothing may still be
+    // running on them when it returns: a late kernel of a failed call would write the arena, Lacc and the pinned
+    // counters of the NEXT call on this handle.  The guard drains them (and keeps the sequence numbers monotonic).
+    struct Drain {
+        trt_handle* h;
+        PassSlot* slots;
+        int n;
+        hipStream_t caller;
+        bool armed = true;
+        ~Drain()
+        {
+            for (int k = 0; k < n; ++k) h->slot_seq[k] = slots[k].seq;
+            if (!armed) return;
+            for (int k = 0; k < n; ++k) (void)hipStreamSynchronize(slots[k].stream);
+            (void)hipStreamSynchronize(caller);
+            (void)hipGetLastError();
+        }
+    } drain{h, slots, slots_used, stream};
     for (int k = 0; k < slots_used; ++k) HIPC(hipStreamWaitEvent(slots[k].stream, ev_begin, 0));
 
     uint32_t next_chunk = 0, resolved_upto = 0;
@@ -673,6 +713,10 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         S.seq++;
         hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, S.stream, S.d_counts, COUNT_STRIDE, S.b, 1u + nl, (volatile uint32_t*)S.host_counts, S.seq);
         S.state = PassSlot::WAIT;
+        if (h->fail_at_bounce >= 0 && (int)S.b == h->fail_at_bounce) {  // test hook: fail with this bounce's kernels in flight
+            h->fail_at_bounce = -1;
+            return fail(TRT_EHIP, "injected failure (TRT_TEST_FAIL_AT_BOUNCE)");
+        }
         return TRT_OK;
     };
     // queue lengths are back: shadow rays of this bounce, then the next bounce / the tail / the end of the pass
@@ -721,8 +765,13 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
             TA.uniform = h->trace_impl == 0 ? 1u : 0u;
             TA.stats = d_stats;
             tm.begin(TRT_K_TAIL, S.stream);
-            if (count) hipLaunchKernelGGL(k_tail<true>, dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
-            else hipLaunchKernelGGL(k_tail<false>, dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+            if (h->node_kind == 1) {
+                if (count) hipLaunchKernelGGL((k_tail<true, 1>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+                else hipLaunchKernelGGL((k_tail<false, 1>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+            } else {
+                if (count) hipLaunchKernelGGL((k_tail<true, 0>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+                else hipLaunchKernelGGL((k_tail<false, 0>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+            }
             tm.end(S.stream);
             st.launches[TRT_K_TAIL]++;
             S.n_active = 0;
@@ -769,6 +818,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     if (accum_host) HIPC(hipMemcpyAsync(accum_host, d_acc, acc_bytes, hipMemcpyDeviceToHost, stream));
     HIPC(hipStreamSynchronize(stream));
     HIPC(hipGetLastError());
+    drain.armed = false;  // everything this call enqueued has completed
 
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, ev_begin, ev_end));
@@ -786,7 +836,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     st.max_bounces = ds.max_depth_hit;
     st.passes = n_chunks;
     st.rows_rendered = rows.size();
-    st.inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (uint32_t)sizeof(WideNode);
+    st.inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(CNode) : (uint32_t)sizeof(WideNode));
     if (stats_out) *stats_out = st;
     return TRT_OK;
 }
@@ -849,9 +899,17 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     HIPC(hipMemcpy(d_dir, dir, in_bytes, hipMemcpyHostToDevice));
     HIPC(hipMemset(d_stats, 0, sizeof(DeviceStats)));
     hipLaunchKernelGGL(k_pack_rays, dim3(std::min<uint32_t>((n32 + 255) / 256, 65536u)), dim3(256), 0, nullptr, d_org, d_dir, ra, rb, n32);
-    hipEvent_t e0, e1;
-    HIPC(hipEventCreate(&e0));
-    HIPC(hipEventCreate(&e1));
+    struct Events {  // destroyed on every path out of this function
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events()
+        {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    HIPC(hipEventCreate(&ev.e0));
+    HIPC(hipEventCreate(&ev.e1));
+    hipEvent_t e0 = ev.e0, e1 = ev.e1;
     HIPC(hipEventRecord(e0, nullptr));
     RaySource src{};
     src.ra = ra;
@@ -862,8 +920,6 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     HIPC(hipGetLastError());
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     std::vector<f4> hh(n);
     HIPC(hipMemcpy(hh.data(), hit, q16, hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < n; ++i) {
@@ -881,7 +937,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
         stats_out->wave_steps[1] = ds.wave_leaf_steps;
         stats_out->kernel_ms[TRT_K_TRACE_CLOSEST] = ms;
         stats_out->launches[TRT_K_TRACE_CLOSEST] = 1;
-        stats_out->inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (uint32_t)sizeof(WideNode);
+        stats_out->inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(CNode) : (uint32_t)sizeof(WideNode));
     }
     return TRT_OK;
 }

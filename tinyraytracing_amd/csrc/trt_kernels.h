@@ -303,7 +303,7 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
     }
 }
 
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
@@ -319,7 +319,7 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySo
         f4 a, b;
         fetchRay<PRIMARY>(sc, src, i, a, b);
         const bool any = SHADOW && any_flag;
-        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
+        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT, NK>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
         if (!SHADOW) {
             hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
         } else if (any ? h.tri < 0 : (h.tri >= 0 && (h.flags >> 8) == light_mat)) {
@@ -338,7 +338,7 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySo
         }
     }
 }
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
@@ -412,7 +412,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             if (m == 0ull) break;
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
-                if (!innerStep(sc, cur, sp, stk, o, inv, best_t)) {
+                if (!innerStep<NK>(sc, cur, sp, stk, o, inv, best_t)) {
                     if (sp != 0) cur = stk.pop(--sp);
                     else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }  // nothing in front of the hint: search again without it
                     else cur = TRT_REF_DONE;
@@ -445,6 +445,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                         const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
                         take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
                     }
+                    if (NK == 1 && take) take = leafBoxPasses(sc, first, o, inv);  // compressed nodes: the leaf's exact box decides
                     if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
                 }
                 if (any && best_tri >= 0) cur = TRT_REF_DONE;
@@ -463,7 +464,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             // ---- inner-node step
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
-                if (innerStep(sc, cur, sp, stk, o, inv, best_t)) { lk = 0; lt = TRT_INF; li = -1; }
+                if (innerStep<NK>(sc, cur, sp, stk, o, inv, best_t)) { lk = 0; lt = TRT_INF; li = -1; }
                 else adv = true;
             }
         } else {
@@ -488,6 +489,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                             const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
                             take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
                         }
+                        if (NK == 1 && take) take = leafBoxPasses(sc, first, o, inv);  // compressed nodes: the leaf's exact box decides
                         if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
                     }
                     adv = true;
@@ -514,31 +516,31 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
     }
 }
 
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueue(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
 {
     if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats, any_flag, reinterpret_cast<f4*>(smem));
-    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
-    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
+    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
+    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
 }
 
 // PRIMARY: bounce 0 — ray i is the camera ray of path i, generated in registers (K1 of SURVEY.md §7 fused
 // into K2: no primary-ray queue is ever written or read).
-template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY>
+template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
 {
     __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : DEPTH * TRT_TRACE_BLOCK];  // stack, or (uniform walk) the candidate queue
-    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false);
+    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false);
 }
 
 // Shadow test of shade() (pathTracing.cpp:51-58): CLOSEST hit, visible iff
 // its material is the light's (Q5); then L += w.  One launch per light, in
 // light order; each path has at most one ray per launch, so the read-modify-
 // write of Lacc needs no atomic and the sum order is fixed.
-template <bool COUNT, int DEPTH, bool SPILL, int IMPL>
+template <bool COUNT, int DEPTH, bool SPILL, int IMPL, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any)
 {
@@ -547,7 +549,7 @@ __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uin
     src.ra = sq.sa;
     src.rb = sq.sb;
     src.s0 = 0;
-    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u);
+    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false, NK>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u);
 }
 
 // Block-wide stream compaction in two halves.  blockStage: every thread calls it with its `flag`; wave
@@ -729,7 +731,7 @@ struct TailArgs {
     DeviceStats* stats;
 };
 
-template <bool COUNT>
+template <bool COUNT, int NK>
 __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs A)
 {
     __shared__ __attribute__((aligned(16))) uint32_t smem[TRT_LDS_STACK_MAX * TRT_TRACE_BLOCK];  // the stacks, or (uniform) the candidate queues
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
                     if (triTest(sc.tri_isect[h.tri], o, d, t, un, vn, det)) { h.u = un / det; h.v = vn / det; }
                 }
             } else {
-                h = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni[0], nt[0]);
+                h = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT, NK>(sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni[0], nt[0]);
             }
             ShadeCtx c;
             shadeBegin(sc, A.td, A.s0, ra, rb, bt, mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v), c);
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
                     sh.t = fixed ? t_max : TRT_INF; sh.tri = -1; sh.flags = 0u; sh.u = 0.f; sh.v = 0.f;
                     uniformWalk<COUNT>(sc, c.vx.P, wo, true, reinterpret_cast<f4*>(smem) + threadIdx.x, sh.t, sh.tri, sh.flags, ni[1], nt[1]);
                 } else {
-                    sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT>(sc, c.vx.P, wo, stk, ni[1], nt[1], t_max, fixed, !fixed);
+                    sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT, NK>(sc, c.vx.P, wo, stk, ni[1], nt[1], t_max, fixed, !fixed);
                 }
                 if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)sc.lights[li].mat)) { L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z; }
             }
