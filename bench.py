@@ -6,11 +6,18 @@ example-scenes-cg22 at 1920x1080, 256 spp — the configuration BASELINE.json's 
 With N > 1 the image rows are dealt to the ranks in interleaved 8-row stripes and gathered on rank 0
 with a single RCCL gather inside the timed region (total work fixed: strong scaling).
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement for every field).
+Prints ONE JSON line on rank 0 (DESIGN.md §5 explains every field):
+  value / ms_per_step     wall clock of the K timed steps (barrier + synchronize on both sides, max over ranks)
+  roofline                dominant kernel of the headline: algorithmic bytes (SURVEY.md §8d canonical sizes x counts
+                          from an untimed counting render) / that kernel's hipEvent time in the timed steps
+  extra_workloads         (N = 1) the other rows of BASELINE.md §3 — veach-mis, staircase at 1080p/256 spp and the
+                          1 M-triangle soup of config 3 — timed the same way with fewer steps, each with its own roofline
+  cpu_baseline            the oracle ("port") on one socket's physical cores, pinned, in a child process
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +33,9 @@ WORKLOADS = {
     "soup": "synthetic 1M random triangles in the Cornell box (deep BVH stress)",
     "blob": "synthetic displaced geodesic sphere (Stanford-style mesh)",
 }
+SEEDS = {"back": 0x5EED0001, "veach-mis": 0x5EED0002, "staircase": 0x5EED0004, "soup": 0x5EED0003, "blob": 0x5EED0005}
+# (scene, spp, steps): BASELINE.md §3's other rows, timed after the headline when N = 1
+EXTRA = [("veach-mis", 256, 2), ("staircase", 256, 1), ("soup", 64, 2)]
 
 
 def parse():
@@ -42,6 +52,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=None)
     ap.add_argument("--mem-gb", type=float, default=0.0, help="HBM budget for path state (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads (veach-mis, staircase, soup after the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--overlap", action="store_true", help="TRT_FLAG_OVERLAP: two passes in flight (+4-5 %% Mrays/s; per-kernel timings then overlap)")
     ap.add_argument("--fixed-nee", action="store_true", help="TRT_FLAG_FIXED_NEE: unbiased light sampling + occlusion-test shadow rays (not the parity mode; not the headline)")
@@ -51,9 +62,9 @@ def parse():
 
 
 def algorithmic_bytes(st):
-    """SURVEY.md §8d canonical sizes: 32 B per child box + reference of a visited inner node (64 B for a
-    two-child node, 128 B for a four-child one: trt_stats.inner_node_bytes), triangle test 48 B, ray record
-    32 B read, hit record 16 B written, shaded hit 64 B, generated ray 32 B written, framebuffer 12 B / pixel."""
+    """SURVEY.md §8d canonical sizes: 32 B per child box + reference of a visited inner node (64 B for a two-child node
+    or a compressed four-child one, 128 B for an exact four-child one: trt_stats.inner_node_bytes), triangle test 48 B, ray
+    record 32 B read, hit record 16 B written, shaded hit 64 B, generated ray 32 B written, framebuffer 12 B / pixel."""
     closest_rays = st.rays_camera + st.rays_indirect
     nb = st.inner_node_bytes or 64
     b_closest = nb * st.inner_visits[0] + 48 * st.tri_tests[0] + (32 + 16) * closest_rays
@@ -63,11 +74,162 @@ def algorithmic_bytes(st):
     return {"trace_closest": b_closest, "trace_shadow": b_shadow, "shade": b_shade, "gen_primary": b_gen}
 
 
+def traffic_from_profiles(scene, height, spp):
+    """HBM-side bytes per launch measured by rocprofv3 PMC passes of this command in an EARLIER run and committed under
+    profiles/ (tools/prof.sh + tools/pmc_summary.py) — reported beside the live numbers, never as `roofline.traffic`."""
+    tpath = os.path.join(ROOT, "profiles", f"hbm_traffic_{scene}_{height}p_{spp}spp.json")
+    if not os.path.exists(tpath):
+        return None
+    d = json.load(open(tpath))
+    return {"file": os.path.relpath(tpath, ROOT), "source": d.get("source"), "bytes_per_launch": d["bytes_per_launch"]}
+
+
+class Bench:
+    def __init__(self, a, world, rank, local_rank, dist, backend):
+        import torch
+        import tinyraytracing_amd as T
+        from tinyraytracing_amd import dist as D
+        self.a, self.world, self.rank, self.local_rank, self.dist, self.backend = a, world, rank, local_rank, dist, backend
+        self.torch, self.T, self.D = torch, T, D
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def measure(self, scene_name, width, height, spp, steps, warmup, seed, leaf=None, tris=None, base_flags=0, also_overlap=False, save_png=None):
+        """Counting render (untimed), warm-up, then `steps` timed renders of one workload.  Returns the result fields."""
+        T, D, torch, a = self.T, self.D, self.torch, self.a
+        world, rank, local_rank, dist = self.world, self.rank, self.local_rank, self.dist
+        t0 = time.time()
+        scene = T.Scene.named(scene_name, width, height, leaf_num=leaf, n=tris)
+        t_load = time.time() - t0
+        renderer = T.Renderer(scene, local_rank)
+        budget = int(a.mem_gb * (1 << 30))
+        fx = T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0
+        flags_time = T.TRT_FLAG_TIMING | base_flags | fx
+        flags_count = T.TRT_FLAG_TIMING | T.TRT_FLAG_COUNT | fx
+        p_rank = D.shard_params(width, height, spp, seed, rank, world, flags=flags_time, mem_budget=budget)
+        nrows = len(T.rows_selected(p_rank))
+        out = torch.empty((nrows, width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def step(flags):
+            def fn(pp):
+                return out, renderer.render_into(pp, out, stream)
+            # every rank renders its stripes, then ONE gather of the packed stripes to rank 0
+            return D.render_distributed(fn, width, height, spp, seed, dist=dist, device=f"cuda:{local_rank}", flags=flags, mem_budget=budget)
+
+        img, st_count = step(flags_count)  # inner-node visits / triangle tests for the algorithmic bytes
+        for _ in range(max(warmup - 1, 0)):
+            step(flags_time)
+        self.sync()
+        t_begin = time.perf_counter()
+        kernel_ms = [0.0] * 8
+        launches = [0] * 8
+        rays_rank = 0
+        render_ms = 0.0
+        st = st_count
+        for _ in range(steps):
+            img, st = step(flags_time)
+            rays_rank += st.rays
+            render_ms += st.render_ms
+            for k in range(8):
+                kernel_ms[k] += st.kernel_ms[k]
+                launches[k] += st.launches[k]
+        self.sync()
+        elapsed = time.perf_counter() - t_begin
+        # --also-overlap: beside the contract's number, the same steps with two sample passes in flight
+        # (TRT_FLAG_OVERLAP, what render()/tinyrt use).  Not `value`: per-kernel hipEvent times of overlapping passes
+        # contain each other.  Off by default so that a rocprofv3 run of the default command sees the timed launches only.
+        overlap_extra = None
+        if world == 1 and also_overlap and not (base_flags & T.TRT_FLAG_OVERLAP):
+            step(T.TRT_FLAG_OVERLAP | fx)
+            self.sync()
+            t_ov = time.perf_counter()
+            rays_ov = 0
+            for _ in range(steps):
+                rays_ov += step(T.TRT_FLAG_OVERLAP | fx)[1].rays
+            self.sync()
+            t_ov = time.perf_counter() - t_ov
+            overlap_extra = {"value": round(rays_ov / t_ov / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(t_ov / steps * 1e3, 3)}
+        if dist is not None:
+            red_dev = f"cuda:{local_rank}" if self.backend == "nccl" else "cpu"
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            rr = torch.tensor([rays_rank], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(rr)
+            rays_total = int(rr.item())
+        else:
+            rays_total = rays_rank
+        res = None
+        if rank == 0:
+            mrays = rays_total / elapsed / 1e6
+            # roofline of the dominant kernel of THIS rank: algorithmic bytes (counting pass, same seed -> same
+            # counts every step) / its summed launch time in the timed region (hipEvents on the launch stream)
+            by = algorithmic_bytes(st_count)
+            names = T.KERNEL_NAMES
+            dom = max(range(len(names)), key=lambda k: kernel_ms[k])
+            dom_name = names[dom]
+            dom_bytes_step = by.get(dom_name, 0)
+            dom_ms = kernel_ms[dom]
+            achieved = dom_bytes_step * steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None,  # HBM bytes need rocprofv3 --pmc passes (tools/prof.sh); not measurable from inside this process
+                        "launches_per_step": launches[dom] // max(steps, 1),
+                        "avg_launch_ms": round(dom_ms / max(launches[dom], 1), 5),
+                        "algorithmic_bytes_per_launch": int(dom_bytes_step * steps / max(launches[dom], 1)),
+                        "frac_of_measured_copy_peak": round(achieved / 6290.0, 4)}
+            tp = traffic_from_profiles(scene_name, height, spp) if (world == 1 and width * 9 == height * 16) else None
+            if tp and dom_name in tp["bytes_per_launch"] and launches[dom] and dom_ms > 0:
+                tb = tp["bytes_per_launch"][dom_name]
+                meas = tb / (dom_ms / launches[dom] * 1e-3) / 1e9
+                roofline["traffic_from_profiles"] = {"file": tp["file"], "bytes_per_launch": tb, "GBps_at_live_launch_time": round(meas, 1),
+                                                     "frac": round(meas / HBM_PEAK_GBS, 4),
+                                                     "over_algorithmic": round(tb / max(roofline["algorithmic_bytes_per_launch"], 1), 3)}
+            if achieved > HBM_PEAK_GBS:
+                roofline["note"] = ("algorithmic bytes (every node / triangle record a ray touches) exceed the HBM peak because the scene is "
+                                    "served from L1/L2/Infinity Cache; the kernel is bound by VALU/SALU issue and the CU's texture-address rate, not by HBM (DESIGN.md 5)")
+            total_bytes_step = sum(by.values()) + 12 * width * nrows
+            kernels = {names[k]: {"ms_per_step": round(kernel_ms[k] / steps, 3), "launches_per_step": launches[k] // max(steps, 1),
+                                  "algorithmic_GBps": round(by.get(names[k], 0) * steps / (kernel_ms[k] * 1e-3) / 1e9, 1) if kernel_ms[k] > 0 and names[k] in by else None}
+                       for k in range(len(names))}
+            res = {
+                "value": round(mrays, 2), "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+                "data": f"scene '{scene_name}' ({WORKLOADS[scene_name]}), counter RNG seed {seed:#x}",
+                "config": {"workload": f"{WORKLOADS[scene_name]}, {width}x{height}, {spp} spp", "scene": scene_name, "width": width,
+                           "height": height, "spp": spp, "triangles": scene.info["n_triangles"], "bvh_nodes": scene.arrays()["n_nodes"],
+                           "leaf_num": leaf if leaf is not None else T.default_leaf(scene_name, scene.info["n_triangles"]),
+                           "inner_node_bytes": st_count.inner_node_bytes,
+                           "overlap_passes": bool(base_flags & T.TRT_FLAG_OVERLAP), "fixed_nee": bool(a.fixed_nee),
+                           "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
+                "rays_per_step": rays_total // steps,
+                "rays_rank0": {"camera": st.rays_camera, "shadow": st.rays_shadow, "indirect": st.rays_indirect},
+                "device_render_ms_per_step_rank0": round(render_ms / steps, 3),
+                "hbm_algorithmic_GBps_rank0": round(total_bytes_step * steps / (render_ms * 1e-3) / 1e9, 1) if render_ms > 0 else None,
+                "simd_utilisation_traversal": {
+                    "inner_steps": round((st_count.inner_visits[0] + st_count.inner_visits[1]) / (64.0 * st_count.wave_steps[0]), 3) if st_count.wave_steps[0] else None,
+                    "leaf_steps": round((st_count.tri_tests[0] + st_count.tri_tests[1]) / (64.0 * st_count.wave_steps[1]), 3) if st_count.wave_steps[1] else None,
+                    "visits_per_ray": round((st_count.inner_visits[0] + st_count.inner_visits[1]) / max(st_count.rays, 1), 2),
+                    "tri_tests_per_ray": round((st_count.tri_tests[0] + st_count.tri_tests[1]) / max(st_count.rays, 1), 2)},
+                "roofline": roofline, "kernels_rank0": kernels, "passes": st.passes, "max_path_vertices": st.max_bounces + 1,
+                "scene_load_build_s": round(t_load, 2), "with_pass_overlap": overlap_extra,
+            }
+            if save_png and img is not None:
+                T.imshow(img.cpu().numpy(), save_png)
+        renderer.close()
+        del out
+        torch.cuda.empty_cache()
+        return res, scene
+
+
 def main():
     a = parse()
     import torch
     import tinyraytracing_amd as T
-    from tinyraytracing_amd import dist as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -93,138 +255,26 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    seed = a.seed if a.seed is not None else {"back": T.SEED_BACK, "veach-mis": 0x5EED0002, "staircase": T.SEED_STAIRCASE,
-                                               "soup": T.SEED_SOUP, "blob": T.SEED_BLOB}[a.scene]
-    t0 = time.time()
-    scene = T.Scene.named(a.scene, a.width, a.height, leaf_num=a.leaf, n=a.tris)
-    t_load = time.time() - t0
-    renderer = T.Renderer(scene, local_rank)
-    budget = int(a.mem_gb * (1 << 30))
-
-    ov = (T.TRT_FLAG_OVERLAP if a.overlap else 0) | (T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0)
-    p_time = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_TIMING | ov, mem_budget=budget)
-    p_count = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_TIMING | T.TRT_FLAG_COUNT | (T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0), mem_budget=budget)
-    nrows = len(T.rows_selected(p_time))
-    out = torch.empty((nrows, a.width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(p):
-        def fn(pp):
-            st = renderer.render_into(pp, out, stream)
-            return out, st
-        # every rank renders its stripes, then ONE gather of the packed stripes to rank 0
-        return D.render_distributed(fn, a.width, a.height, a.spp, seed, dist=dist, device=f"cuda:{local_rank}",
-                                    flags=p.flags, mem_budget=budget)
-
-    # counting pass (untimed): inner-node visits / triangle tests for the algorithmic bytes
-    img, st_count = step(p_count)
-    for _ in range(max(a.warmup - 1, 0)):
-        step(p_time)
-
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    sync()
-    t_begin = time.perf_counter()
-    kernel_ms = [0.0] * 8
-    launches = [0] * 8
-    rays_rank = 0
-    render_ms = 0.0
-    for _ in range(a.steps):
-        img, st = step(p_time)
-        rays_rank += st.rays
-        render_ms += st.render_ms
-        for k in range(8):
-            kernel_ms[k] += st.kernel_ms[k]
-            launches[k] += st.launches[k]
-    sync()
-    elapsed = time.perf_counter() - t_begin
-    # --also-overlap: beside the contract's number, the same steps with two sample passes in flight
-    # (TRT_FLAG_OVERLAP, what render()/tinyrt use).  Not `value`: per-kernel hipEvent times of overlapping passes
-    # contain each other.  Off by default so that a rocprofv3 run of the default command sees the timed launches only.
-    overlap_extra = None
-    if world == 1 and not a.overlap and a.also_overlap:
-        p_ov = D.shard_params(a.width, a.height, a.spp, seed, rank, world, flags=T.TRT_FLAG_OVERLAP | (T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0), mem_budget=budget)
-        step(p_ov)
-        sync()
-        t_ov = time.perf_counter()
-        rays_ov = 0
-        for _ in range(a.steps):
-            rays_ov += step(p_ov)[1].rays
-        sync()
-        t_ov = time.perf_counter() - t_ov
-        overlap_extra = {"value": round(rays_ov / t_ov / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(t_ov / a.steps * 1e3, 3)}
-    if dist is not None:
-        red_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        rr = torch.tensor([rays_rank], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(rr)
-        rays_total = int(rr.item())
-    else:
-        rays_total = rays_rank
-
+    B = Bench(a, world, rank, local_rank, dist, backend)
+    seed = a.seed if a.seed is not None else SEEDS[a.scene]
+    res, scene = B.measure(a.scene, a.width, a.height, a.spp, a.steps, a.warmup, seed, leaf=a.leaf, tris=a.tris,
+                           base_flags=T.TRT_FLAG_OVERLAP if a.overlap else 0, also_overlap=a.also_overlap, save_png=a.save_png)
     if rank == 0:
-        mrays = rays_total / elapsed / 1e6
-        # roofline of the dominant kernel of THIS rank: algorithmic bytes (counting pass, same seed -> same
-        # counts every step) / its summed launch time in the timed region (hipEvents on the launch stream)
-        by = algorithmic_bytes(st_count)
-        names = T.KERNEL_NAMES
-        dom = max(range(len(names)), key=lambda k: kernel_ms[k])
-        dom_name = names[dom]
-        dom_bytes_step = by.get(dom_name, 0)
-        dom_ms = kernel_ms[dom]
-        achieved = dom_bytes_step * a.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None  # measured HBM bytes per launch of that kernel (PMC passes, committed under profiles/), when this is that workload
-        tpath = os.path.join(ROOT, "profiles", f"hbm_traffic_{a.scene}_{a.height}p_{a.spp}spp.json")
-        if world == 1 and a.width * 9 == a.height * 16 and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["bytes_per_launch"].get(dom_name)
-        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "launches_per_step": launches[dom] // max(a.steps, 1),
-                    "avg_launch_ms": round(dom_ms / max(launches[dom], 1), 5),
-                    "algorithmic_bytes_per_launch": int(dom_bytes_step * a.steps / max(launches[dom], 1)),
-                    "frac_of_measured_copy_peak": round(achieved / 6290.0, 4)}
-        if traffic and launches[dom] and dom_ms > 0:
-            # the same launches' measured HBM-side bytes (PMC passes, profiles/) over the live launch duration
-            meas = traffic / (dom_ms / launches[dom] * 1e-3) / 1e9
-            roofline["traffic_GBps"] = round(meas, 1)
-            roofline["traffic_frac"] = round(meas / HBM_PEAK_GBS, 4)
-        if achieved > HBM_PEAK_GBS:
-            roofline["note"] = ("algorithmic bytes (every node / triangle record a ray touches) exceed the HBM peak because the scene is "
-                                "served from L1/L2/Infinity Cache; the kernel is bound by VALU issue and the L1 tag rate, not by HBM (DESIGN.md 5)")
-        total_bytes_step = sum(by.values()) + 12 * a.width * nrows
-        kernels = {names[k]: {"ms_per_step": round(kernel_ms[k] / a.steps, 3), "launches_per_step": launches[k] // max(a.steps, 1),
-                              "algorithmic_GBps": round(by.get(names[k], 0) * a.steps / (kernel_ms[k] * 1e-3) / 1e9, 1) if kernel_ms[k] > 0 and names[k] in by else None}
-                   for k in range(len(names))}
-        result = {
-            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": f"scene '{a.scene}' ({WORKLOADS[a.scene]}), counter RNG seed {seed:#x}",
-            "config": {"workload": f"{WORKLOADS[a.scene]}, {a.width}x{a.height}, {a.spp} spp", "scene": a.scene, "width": a.width,
-                       "height": a.height, "spp": a.spp, "triangles": scene.info["n_triangles"], "bvh_nodes": scene.arrays()["n_nodes"],
-                       "leaf_num": a.leaf if a.leaf is not None else T.default_leaf(a.scene, scene.info["n_triangles"]), "overlap_passes": bool(a.overlap), "fixed_nee": bool(a.fixed_nee), "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
-            "rays_per_step": rays_total // a.steps,
-            "rays_rank0": {"camera": st.rays_camera, "shadow": st.rays_shadow, "indirect": st.rays_indirect},
-            "device_render_ms_per_step_rank0": round(render_ms / a.steps, 3),
-            "hbm_algorithmic_GBps_rank0": round(total_bytes_step * a.steps / (render_ms * 1e-3) / 1e9, 1) if render_ms > 0 else None,
-            "simd_utilisation_traversal": {
-                "inner_steps": round((st_count.inner_visits[0] + st_count.inner_visits[1]) / (64.0 * st_count.wave_steps[0]), 3) if st_count.wave_steps[0] else None,
-                "leaf_steps": round((st_count.tri_tests[0] + st_count.tri_tests[1]) / (64.0 * st_count.wave_steps[1]), 3) if st_count.wave_steps[1] else None,
-                "visits_per_ray": round((st_count.inner_visits[0] + st_count.inner_visits[1]) / max(st_count.rays, 1), 2),
-                "tri_tests_per_ray": round((st_count.tri_tests[0] + st_count.tri_tests[1]) / max(st_count.rays, 1), 2)},
-            "roofline": roofline, "kernels_rank0": kernels, "passes": st.passes, "max_path_vertices": st.max_bounces + 1,
-            "scene_load_build_s": round(t_load, 2), "with_pass_overlap": overlap_extra,
-        }
-        if a.save_png and img is not None:
-            T.imshow(img.cpu().numpy(), a.save_png)
+        result = {"metric": "Mrays/s", "value": res["value"], "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                  "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32"}
+        result.update({k: v for k, v in res.items() if k not in result})
+        headline = (a.scene, a.width, a.height, a.spp) == ("back", 1920, 1080, 256)
+        if world == 1 and headline and not a.no_extra and not a.fixed_nee and not a.overlap:
+            extra = []
+            for name, spp, steps in EXTRA:
+                r, sc = B.measure(name, a.width, a.height, spp, steps, 1, SEEDS[name])
+                extra.append({k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "rays_per_step", "roofline", "kernels_rank0", "simd_utilisation_traversal")})
+                sc.close()
+            result["extra_workloads"] = extra
         if world == 1 and not a.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(a, scene, seed)
-            result["gpu_over_cpu"] = round(mrays / result["cpu_baseline"]["value"], 1)
+            result["cpu_baseline"] = cpu_baseline(a, seed)
+            if result["cpu_baseline"] and result["cpu_baseline"].get("value"):
+                result["gpu_over_cpu"] = round(res["value"] / result["cpu_baseline"]["value"], 1)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
@@ -233,23 +283,24 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, scene, seed):
-    """The oracle (oracle/liboracle.so: the reference algorithm — unordered, unculled traversal — restated
-    in C++ with OpenMP over rows) timed on this box's host cores on a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    import tinyraytracing_amd as T
-    threads = len(os.sched_getaffinity(0))
-    fx = T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0
-    p1 = T.make_params(a.width, a.height, 1, seed, flags=fx)
-    _, s1 = O.render(scene.flat, p1, threads=threads)
-    spp = int(max(1, min(a.spp, a.cpu_seconds / max(s1.seconds, 1e-3))))
-    if spp > 1:
-        _, s = O.render(scene.flat, T.make_params(a.width, a.height, spp, seed, flags=fx), threads=threads)
-    else:
-        s = s1
-    return {"value": round(s.rays / s.seconds / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{a.scene} {a.width}x{a.height}, {spp} spp of every pixel ({s.rays} rays, {s.seconds:.2f} s), OpenMP over rows"}
+def cpu_baseline(a, seed):
+    """The oracle (oracle/liboracle.so: the reference algorithm — unordered, unculled traversal — restated in C++ with
+    OpenMP over rows) timed on ONE socket's physical cores of this box, one pinned thread per core, on a bounded sample
+    of the same workload.  Runs in a child process (tools/cpu_baseline.py) so that OMP_PLACES /
+    OMP_PROC_BIND take effect before any OpenMP runtime is initialised, and so that it never shares this process' GPU."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--scene", a.scene, "--width", str(a.width), "--height", str(a.height),
+           "--spp", str(a.spp), "--seed", hex(seed), "--seconds", str(a.cpu_seconds)]
+    if a.tris:
+        cmd += ["--tris", str(a.tris)]
+    if a.leaf:
+        cmd += ["--leaf", str(a.leaf)]
+    if a.fixed_nee:
+        cmd += ["--fixed-nee"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
+        return json.loads(out)
+    except Exception as e:  # a baseline that could not run is reported as such, never guessed
+        return {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
 
 if __name__ == "__main__":

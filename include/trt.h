@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TRT_ABI_VERSION 2
+#define TRT_ABI_VERSION 3
 
 /* error codes */
 #define TRT_OK 0
@@ -233,6 +233,24 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
                       float* t, int32_t* tri, float* uv, trt_stats* stats);
 
 void trt_destroy(trt_handle* h);
+
+/* ---- one node, several GPUs -------------------------------------------------------------------------------------
+ * The sample/pixel loop has no cross-pixel dependency (main.cpp:84-108), so the image is tiled: the scene is replicated
+ * on every device of the group, the rows of the tile are dealt to the devices in interleaved stripes of `row_block` rows
+ * (device k renders the rows y with (y / row_block) % n == k), every device renders its stripes on its own host thread
+ * (trt_render_device), and ONE ncclGather (RCCL over xGMI; /opt/rocm/include/rccl/rccl.h:745, communicators from
+ * ncclCommInitAll :236) brings the packed stripes to devices[0], which un-interleaves them.  The random streams are keyed
+ * by the global (pixel, sample), so the image is bit-identical to trt_render's for every n and every row_block.
+ * RCCL is loaded (dlopen librccl.so.1) by trt_group_create only when the group spans more than one DISTINCT device;
+ * a group whose entries name the same device several times (a rehearsal on a one-GPU box) gathers with device copies. */
+typedef struct trt_group trt_group;
+int trt_group_create(const trt_scene* scene, int n_devices, const int* devices, trt_group** out);
+/* p: as for trt_render (tile, spp, seed, flags); p->row_block (>= 1; 0 = 8) is the stripe height, row_mod / row_rem are
+ * set by the library.  out_rgb_host: (y1-y0) * (x1-x0) * 3 floats.  stats (optional): rays / launches / kernel_ms summed
+ * over the devices, render_ms = the slowest device's, plus gather_ms = gather + un-interleave on devices[0]. */
+int trt_group_render(trt_group* g, const trt_params* p, float* out_rgb_host, trt_stats* stats, double* gather_ms);
+int trt_group_size(const trt_group* g);
+void trt_group_destroy(trt_group* g);
 
 const char* trt_last_error(void);
 

@@ -253,6 +253,45 @@ class Renderer:
             pass
 
 
+class GroupRenderer:
+    """Owns a trt_group: the scene resident on several GPUs of one node; render() tiles the image over them in
+    interleaved row stripes and gathers with ONE ncclGather on the first device (include/trt.h).  `devices` may name one
+    device several times (a rehearsal on a one-GPU box: same code path, device copies instead of RCCL)."""
+
+    def __init__(self, scene, devices):
+        self._lib = _abi.load_hip()
+        self._scene = scene
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        g = C.c_void_p()
+        rc = self._lib.trt_group_create(scene.flat, len(devices), devs, C.byref(g))
+        if rc != 0:
+            raise TrtError(f"trt_group_create failed ({rc}): {self._lib.trt_last_error().decode()}")
+        self._g = g
+        self.devices = list(devices)
+
+    def render(self, params):
+        """-> (float32 image [tile rows, tile_w, 3], Stats summed over the devices, gather + un-interleave ms)."""
+        th, tw = params.y1 - params.y0, params.x1 - params.x0
+        out = np.empty((th, tw, 3), dtype=np.float32)
+        st = Stats()
+        gms = C.c_double(0.0)
+        rc = self._lib.trt_group_render(self._g, C.byref(params), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st), C.byref(gms))
+        if rc != 0:
+            raise TrtError(f"trt_group_render failed ({rc}): {self._lib.trt_last_error().decode()}")
+        return out, st, gms.value
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.trt_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def tonemap(image):
     """imshow()'s transfer: (uchar) clamp(pow(x, 1/2.2f) * 255, 0, 255) (main.cpp:34-36)."""
     lib = _abi.load_host()

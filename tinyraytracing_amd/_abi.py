@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-TRT_ABI_VERSION = 2
+TRT_ABI_VERSION = 3
 TRT_INF = 114514.0
 TRT_FLAG_TIMING = 1
 TRT_FLAG_COUNT = 2
@@ -82,7 +82,7 @@ class Stats(C.Structure):
 
 # the symbols include/trt.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = ["trt_rows_selected", "trt_create", "trt_render", "trt_render_device", "trt_render_samples", "trt_trace_closest",
-               "trt_destroy", "trt_last_error", "trt_abi_version"]
+               "trt_destroy", "trt_last_error", "trt_abi_version", "trt_group_create", "trt_group_render", "trt_group_size", "trt_group_destroy"]
 HOST_SYMBOLS = ["trth_scene_load", "trth_scene_drop_tris", "trth_scene_add_soup", "trth_scene_add_blob",
                 "trth_scene_build", "trth_scene_flat", "trth_scene_info", "trth_scene_light_area",
                 "trth_scene_material_name", "trth_scene_free", "trth_tonemap", "trth_write_png",
@@ -168,6 +168,11 @@ def load_hip():
                                       C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(Stats)]
     lib.trt_destroy.argtypes = [C.c_void_p]
     lib.trt_destroy.restype = None
+    lib.trt_group_create.argtypes = [C.POINTER(SceneFlat), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    lib.trt_group_render.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(Stats), C.POINTER(C.c_double)]
+    lib.trt_group_size.argtypes = [C.c_void_p]
+    lib.trt_group_destroy.argtypes = [C.c_void_p]
+    lib.trt_group_destroy.restype = None
     if lib.trt_abi_version() != TRT_ABI_VERSION:
         raise RuntimeError("libtrt_hip.so ABI version mismatch")
     _hip = lib

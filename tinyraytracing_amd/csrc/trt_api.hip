@@ -3,6 +3,8 @@
 // traversal entry.  No CPU compute path exists in this library.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +13,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "trt.h"
@@ -938,6 +941,216 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
         stats_out->kernel_ms[TRT_K_TRACE_CLOSEST] = ms;
         stats_out->launches[TRT_K_TRACE_CLOSEST] = 1;
         stats_out->inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(CNode) : (uint32_t)sizeof(WideNode));
+    }
+    return TRT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ device groups
+namespace {
+// The five RCCL entry points the gather needs, bound at run time: a single-GPU user of this library never loads RCCL.
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Gather)(const void* send, void* recv, size_t count, int datatype, int root, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load(std::string& err)
+    {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("cannot load librccl.so.1: ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("librccl: missing symbol ") + n; return p; };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        Gather = reinterpret_cast<decltype(Gather)>(sym("ncclGather"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Gather && GetErrorString;
+    }
+};
+constexpr int NCCL_FLOAT32 = 7;  // ncclFloat32 (rccl.h ncclDataType_t)
+
+// packed stripes of rank r (rows in increasing y) -> their rows of the tile image
+__global__ __launch_bounds__(256) void k_uninterleave(const float* __restrict__ gathered, float* __restrict__ image, uint32_t tile_rows, uint32_t row_floats,
+                                                       uint32_t row_block, uint32_t n_ranks, uint32_t pad_rows)
+{
+    const uint64_t total = (uint64_t)tile_rows * row_floats;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t y = (uint32_t)(i / row_floats), x = (uint32_t)(i - (uint64_t)y * row_floats);
+        const uint32_t stripe = y / row_block, rank = stripe % n_ranks;
+        const uint32_t packed = (stripe / n_ranks) * row_block + (y - stripe * row_block);  // row of y inside rank's packed buffer
+        image[i] = gathered[((uint64_t)rank * pad_rows + packed) * row_floats + x];
+    }
+}
+}  // namespace
+
+struct trt_group {
+    std::vector<trt_handle*> handles;
+    std::vector<int> devices;
+    bool distinct = false;       // every entry another device: RCCL gathers; else device copies (one-GPU rehearsal)
+    Rccl rccl;
+    std::vector<void*> comms;
+    std::vector<hipStream_t> streams;
+    std::vector<DevBuf> stripe;  // per rank: its packed stripes, padded to the largest rank's row count
+    DevBuf gathered, image;      // on devices[0]
+    ~trt_group()
+    {
+        for (size_t k = 0; k < handles.size(); ++k) {
+            (void)hipSetDevice(devices[k]);
+            if (k < stripe.size()) stripe[k].release();
+            if (k < streams.size() && streams[k]) (void)hipStreamDestroy(streams[k]);
+            if (k < comms.size() && comms[k]) (void)rccl.CommDestroy(comms[k]);
+            trt_destroy(handles[k]);
+        }
+        if (!devices.empty()) (void)hipSetDevice(devices[0]);
+        gathered.release();
+        image.release();
+        if (rccl.lib) dlclose(rccl.lib);
+    }
+};
+
+extern "C" {
+
+int trt_group_size(const trt_group* g) { return g ? (int)g->handles.size() : 0; }
+
+void trt_group_destroy(trt_group* g) { delete g; }
+
+int trt_group_create(const trt_scene* scene, int n_devices, const int* devices, trt_group** out)
+{
+    if (!scene || !devices || !out || n_devices < 1 || n_devices > 64) return fail(TRT_EINVAL, "trt_group_create: bad argument");
+    *out = nullptr;
+    std::unique_ptr<trt_group> g(new trt_group);
+    g->distinct = true;
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = a + 1; b < n_devices; ++b)
+            if (devices[a] == devices[b]) g->distinct = false;
+    for (int k = 0; k < n_devices; ++k) {
+        trt_handle* h = nullptr;
+        if (int e = trt_create(scene, devices[k], &h)) return e;  // message already set
+        g->handles.push_back(h);
+        g->devices.push_back(devices[k]);
+    }
+    g->stripe.resize(n_devices);
+    g->streams.assign(n_devices, nullptr);
+    for (int k = 0; k < n_devices; ++k) {
+        HIPC(hipSetDevice(devices[k]));
+        HIPC(hipStreamCreateWithFlags(&g->streams[k], hipStreamNonBlocking));
+    }
+    if (n_devices > 1 && g->distinct) {
+        std::string err;
+        if (!g->rccl.load(err)) return fail(TRT_EHIP, err);
+        g->comms.assign(n_devices, nullptr);
+        const int rc = g->rccl.CommInitAll(g->comms.data(), n_devices, devices);
+        if (rc != 0) return fail(TRT_EHIP, std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(rc));
+    }
+    *out = g.release();
+    return TRT_OK;
+}
+
+int trt_group_render(trt_group* g, const trt_params* p_in, float* out_host, trt_stats* stats_out, double* gather_ms_out)
+{
+    if (!g || !p_in || !out_host) return fail(TRT_EINVAL, "trt_group_render: null argument");
+    const int n = (int)g->handles.size();
+    trt_params p = *p_in;
+    if (p.row_block <= 0) p.row_block = 8;
+    p.row_mod = n;
+    p.row_rem = 0;
+    if (int e = checkParams(g->handles[0], &p)) return e;
+    const uint32_t tile_rows = (uint32_t)(p.y1 - p.y0), tw = (uint32_t)(p.x1 - p.x0), row_floats = tw * 3u;
+    // The interleave of trt_params counts stripes from image row 0, the group from the tile's first row: the tile is
+    // rendered as its own interleave domain by shifting nothing — rows are selected on absolute y, so the packed index
+    // used by k_uninterleave must be computed on absolute y as well.  Keep it simple: require y0 to be stripe aligned.
+    if (p.y0 % (p.row_block * n) != 0) return fail(TRT_EINVAL, "trt_group_render: y0 must be a multiple of row_block * group size");
+    uint32_t pad_rows = 0;
+    std::vector<uint32_t> rows_of(n);
+    for (int k = 0; k < n; ++k) {
+        trt_params pk = p;
+        pk.row_rem = k;
+        rows_of[k] = (uint32_t)std::max(trt_rows_selected(&pk), 0);
+        pad_rows = std::max(pad_rows, rows_of[k]);
+    }
+    const size_t stripe_bytes = (size_t)pad_rows * row_floats * sizeof(float);
+    for (int k = 0; k < n; ++k) {
+        HIPC(hipSetDevice(g->devices[k]));
+        if (int e = g->stripe[k].ensure(stripe_bytes)) return e;
+    }
+    HIPC(hipSetDevice(g->devices[0]));
+    if (int e = g->gathered.ensure(stripe_bytes * (size_t)n)) return e;
+    if (int e = g->image.ensure((size_t)tile_rows * row_floats * sizeof(float))) return e;
+
+    // ---- every device renders its stripes on its own host thread
+    std::vector<int> rcs(n, TRT_OK);
+    std::vector<std::string> msgs(n);
+    std::vector<trt_stats> sts(n);
+    std::vector<std::thread> threads;
+    for (int k = 0; k < n; ++k) {
+        threads.emplace_back([&, k]() {
+            trt_params pk = p;
+            pk.row_rem = k;
+            if (rows_of[k] == 0) { std::memset(&sts[k], 0, sizeof(trt_stats)); return; }  // more devices than stripes
+            rcs[k] = trt_render_device(g->handles[k], &pk, (float*)g->stripe[k].p, g->streams[k], &sts[k]);
+            if (rcs[k]) msgs[k] = trt_last_error();  // thread-local in the worker: carried over by hand
+        });
+    }
+    for (auto& t : threads) t.join();
+    for (int k = 0; k < n; ++k)
+        if (rcs[k]) return fail(rcs[k], "device " + std::to_string(g->devices[k]) + ": " + msgs[k]);
+
+    // ---- ONE gather to devices[0], then un-interleave there
+    HIPC(hipSetDevice(g->devices[0]));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Ev { hipEvent_t& a; hipEvent_t& b; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev{e0, e1};
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, g->streams[0]));
+    const size_t count = (size_t)pad_rows * row_floats;
+    if (n > 1 && g->distinct) {
+        int rc = g->rccl.GroupStart();
+        for (int k = 0; k < n && rc == 0; ++k) {
+            HIPC(hipSetDevice(g->devices[k]));
+            rc = g->rccl.Gather(g->stripe[k].p, k == 0 ? g->gathered.p : nullptr, count, NCCL_FLOAT32, 0, g->comms[k], g->streams[k]);
+        }
+        const int rc_end = g->rccl.GroupEnd();
+        if (rc == 0) rc = rc_end;
+        if (rc != 0) return fail(TRT_EHIP, std::string("ncclGather: ") + g->rccl.GetErrorString(rc));
+        for (int k = 1; k < n; ++k) { HIPC(hipSetDevice(g->devices[k])); HIPC(hipStreamSynchronize(g->streams[k])); }
+        HIPC(hipSetDevice(g->devices[0]));
+    } else {
+        for (int k = 0; k < n; ++k)
+            HIPC(hipMemcpyAsync((char*)g->gathered.p + stripe_bytes * (size_t)k, g->stripe[k].p, stripe_bytes, hipMemcpyDeviceToDevice, g->streams[0]));
+    }
+    const uint64_t total = (uint64_t)tile_rows * row_floats;
+    hipLaunchKernelGGL(k_uninterleave, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536ull)), dim3(256), 0, g->streams[0], (const float*)g->gathered.p,
+                       (float*)g->image.p, tile_rows, row_floats, (uint32_t)p.row_block, (uint32_t)n, pad_rows);
+    HIPC(hipEventRecord(e1, g->streams[0]));
+    HIPC(hipMemcpyAsync(out_host, g->image.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, g->streams[0]));
+    HIPC(hipStreamSynchronize(g->streams[0]));
+    HIPC(hipGetLastError());
+    float gms = 0.f;
+    HIPC(hipEventElapsedTime(&gms, e0, e1));
+    if (gather_ms_out) *gather_ms_out = gms;
+    if (stats_out) {
+        trt_stats t;
+        std::memset(&t, 0, sizeof(t));
+        for (int k = 0; k < n; ++k) {
+            const trt_stats& s = sts[k];
+            t.rays_camera += s.rays_camera; t.rays_shadow += s.rays_shadow; t.rays_indirect += s.rays_indirect; t.shaded_hits += s.shaded_hits;
+            for (int i = 0; i < 2; ++i) { t.inner_visits[i] += s.inner_visits[i]; t.tri_tests[i] += s.tri_tests[i]; t.wave_steps[i] += s.wave_steps[i]; }
+            for (int i = 0; i < TRT_MAX_KERNELS; ++i) { t.launches[i] += s.launches[i]; t.kernel_ms[i] += s.kernel_ms[i]; }
+            t.render_ms = std::max(t.render_ms, s.render_ms);
+            t.passes = std::max(t.passes, s.passes);
+            t.max_bounces = std::max(t.max_bounces, s.max_bounces);
+            t.rows_rendered += s.rows_rendered;
+            t.inner_node_bytes = std::max(t.inner_node_bytes, s.inner_node_bytes);
+        }
+        *stats_out = t;
     }
     return TRT_OK;
 }

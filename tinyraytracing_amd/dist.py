@@ -21,15 +21,20 @@ def shard_params(width, height, spp, seed, rank, world, row_block=ROW_BLOCK, **k
     return make_params(width, height, spp, seed, rows=(row_block, world, rank) if world > 1 else None, **kw)
 
 
+_max_rows_cache = {}
+
+
 def max_rows(width, height, world, row_block=ROW_BLOCK):
-    """Rows of the most loaded rank (the gather uses equal-sized, padded buffers)."""
+    """Rows of the most loaded rank (the gather uses equal-sized, padded buffers).  Rank 0 owns the first stripe of every
+    round, so it is never behind: full rounds of `world` stripes give every rank row_block rows each, and the remainder
+    goes to the lowest ranks first."""
     if world <= 1:
         return height
-    best = 0
-    for r in range(world):
-        n = sum(1 for y in range(height) if (y // row_block) % world == r)
-        best = max(best, n)
-    return best
+    key = (height, world, row_block)
+    if key not in _max_rows_cache:
+        rounds, rest = divmod(height, row_block * world)
+        _max_rows_cache[key] = rounds * row_block + min(rest, row_block)
+    return _max_rows_cache[key]
 
 
 def assemble(stripes, width, height, world, row_block=ROW_BLOCK):

@@ -17,7 +17,7 @@
 static void usage()
 {
     std::fprintf(stderr,
-                 "usage: tinyrt <basedir> <mtl> <xml> <obj> <spp> [--width W --height H] [--seed S] [--device D]\n"
+                 "usage: tinyrt <basedir> <mtl> <xml> <obj> <spp> [--width W --height H] [--seed S] [--device D | --gpus N | --devices a,b,..]\n"
                  "              [--leaf N] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels]\n"
                  "              [--every N] [--checkpoint file.acc] [--stop-after M]\n"
                  "                                                    progressive: N samples per step, image rewritten after\n"
@@ -42,6 +42,22 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--height")) height = std::atoi(need("--height"));
         else if (!std::strcmp(argv[i], "--seed")) opts.seed = (uint32_t)std::strtoul(need("--seed"), nullptr, 0);
         else if (!std::strcmp(argv[i], "--device")) opts.device = std::atoi(need("--device"));
+        else if (!std::strcmp(argv[i], "--gpus")) {  // devices 0..N-1 of this node: image tiled in row stripes, one RCCL gather
+            const int n = std::atoi(need("--gpus"));
+            opts.devices.clear();
+            for (int d = 0; d < n; ++d) opts.devices.push_back(d);
+        } else if (!std::strcmp(argv[i], "--devices")) {  // explicit list; one device may appear several times (rehearsal on one GPU)
+            opts.devices.clear();
+            const std::string list = need("--devices");
+            size_t pos = 0;
+            while (pos < list.size()) {
+                const size_t c = list.find(',', pos);
+                opts.devices.push_back(std::atoi(list.substr(pos, c == std::string::npos ? std::string::npos : c - pos).c_str()));
+                if (c == std::string::npos) break;
+                pos = c + 1;
+            }
+        }
+        else if (!std::strcmp(argv[i], "--row-block")) opts.row_block = std::atoi(need("--row-block"));
         else if (!std::strcmp(argv[i], "--leaf")) opts.leaf_num = std::atoi(need("--leaf"));
         else if (!std::strcmp(argv[i], "--max-depth")) opts.max_depth = std::atoi(need("--max-depth"));
         else if (!std::strcmp(argv[i], "--out")) out_path = need("--out");

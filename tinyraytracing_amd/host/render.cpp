@@ -55,8 +55,6 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
     FlatScene flat;
     flat.build(scene, bvh);
 
-    trt_handle* h = nullptr;
-    if (trt_create(flat.c_scene(), opts.device, &h) != TRT_OK) throw std::runtime_error(std::string("trt_create: ") + trt_last_error());
     trt_params p{};
     p.width = scene.img_width;
     p.height = scene.img_height;
@@ -70,7 +68,23 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
     std::vector<float> out((size_t)p.width * p.height * 3);
     int rc = TRT_OK;
     std::string msg;
-    if (opts.every <= 0 && opts.checkpoint.empty() && !opts.on_progress && opts.stop_after <= 0) {
+    const bool progressive = !(opts.every <= 0 && opts.checkpoint.empty() && !opts.on_progress && opts.stop_after <= 0);
+    if (opts.devices.size() > 1) {
+        // several GPUs: one host thread and one replica of the scene per device, one gather (trt_group_render)
+        if (progressive) throw std::runtime_error("progressive / check-pointed renders run on one device");
+        trt_group* g = nullptr;
+        if (trt_group_create(flat.c_scene(), (int)opts.devices.size(), opts.devices.data(), &g) != TRT_OK) throw std::runtime_error(std::string("trt_group_create: ") + trt_last_error());
+        p.row_block = opts.row_block > 0 ? opts.row_block : 8;
+        rc = trt_group_render(g, &p, out.data(), stats, nullptr);
+        if (rc) msg = trt_last_error();
+        trt_group_destroy(g);
+        if (rc != TRT_OK) throw std::runtime_error("trt_group_render: " + msg);
+        for (size_t i = 0; i < out.size(); ++i) image[i] += (double)out[i];
+        return;
+    }
+    trt_handle* h = nullptr;
+    if (trt_create(flat.c_scene(), opts.devices.size() == 1 ? opts.devices[0] : opts.device, &h) != TRT_OK) throw std::runtime_error(std::string("trt_create: ") + trt_last_error());
+    if (!progressive) {
         rc = trt_render(h, &p, out.data(), stats);
         if (rc) msg = trt_last_error();
     } else {

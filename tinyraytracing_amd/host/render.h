@@ -16,6 +16,9 @@ struct RenderOpts {
     int spp = 256;            // SAMPLE (main.cpp:13)
     uint32_t seed = 0x5EED0001u;
     int device = 0;
+    std::vector<int> devices;  // more than one entry: the image is tiled over these GPUs of the node in interleaved row stripes and
+                               // gathered with one ncclGather on devices[0] (trt_group_*, include/trt.h); `device` is then ignored
+    int row_block = 8;        // stripe height of that tiling
     int leaf_num = 2;         // the reference calls buildBVH(..., 8) (main.cpp:76); 2 is fastest on the GPU
     BvhBuilder builder = BVH_AUTO;
     int max_depth = 0;
