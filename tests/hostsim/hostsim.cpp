@@ -13,7 +13,7 @@
 using namespace trtd;
 
 namespace {
-int g_node_kind = 1;  // hostsim_set_node_kind
+int g_node_kind = 0;  // hostsim_set_node_kind: what trt_create picks by default (exact wide nodes); 1 = compressed nodes where the tree allows them
 struct ArrayStack {
     uint32_t s[1024];
     void push(int sp, uint32_t v) { s[sp] = v; }
@@ -31,7 +31,7 @@ struct HostScene {
     std::vector<LightTriDev> ltris;
     WideTree wide;
     CompressedTree comp;
-    int nk = 0;  // node kind the traversal walks: 0 exact wide nodes, 1 compressed (trt_create's default when the tree allows it)
+    int nk = 0;  // node kind the traversal walks: 0 exact wide nodes (trt_create's default), 1 compressed (TRT_NODE_KIND=1)
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
     {
@@ -91,7 +91,7 @@ struct HostScene {
 };
 }  // namespace
 
-// 0: exact wide nodes; 1 (default): compressed nodes where the tree allows them.  Returns the previous setting.
+// 0 (default, as trt_create): exact wide nodes; 1: compressed nodes where the tree allows them.  Returns the previous setting.
 extern "C" int hostsim_set_node_kind(int nk)
 {
     const int old = g_node_kind;

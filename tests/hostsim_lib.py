@@ -25,7 +25,7 @@ def lib():
 
 
 def set_node_kind(nk):
-    """0 = exact 4-wide nodes, 1 = compressed nodes (the default wherever the tree is nested); returns the old setting."""
+    """0 = exact 4-wide nodes (the default, as in trt_create), 1 = compressed 64-B nodes wherever the tree is nested; returns the old setting."""
     return lib().hostsim_set_node_kind(int(nk))
 
 

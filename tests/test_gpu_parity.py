@@ -607,3 +607,28 @@ def test_two_rank_gloo_render_with_the_hip_renderer(tmp_path):
     ref, st = O.render(s.flat, T.make_params(96, 54, 8, T.SEED_STAIRCASE))
     assert np.array_equal(got["image"], ref)
     assert int(got["rays"][0]) == st.rays
+
+
+def test_compressed_nodes_on_the_gpu(monkeypatch):
+    """TRT_NODE_KIND=1: the 64-B quantised nodes + exact leaf-box acceptance through every driver the scene can use."""
+    s = get_scene("staircase", 96, 54)
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(100000, lo - 5, hi + 5, seed=8)
+    o2, d2 = raygen.adversarial_rays(s, 20000)
+    org, dirs = np.vstack([org, o2]), np.vstack([dirs, d2])
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    p = T.make_params(96, 54, 8, T.SEED_STAIRCASE)
+    ref, ost = O.render(s.flat, p)
+    monkeypatch.setenv("TRT_NODE_KIND", "1")
+    for impl in ("1", "2", "3"):
+        monkeypatch.setenv("TRT_TRACE_IMPL", impl)
+        r = T.Renderer(s, 0)
+        try:
+            t1, tri1, uv1, st = r.trace_closest(org, dirs, want_stats=True)
+            assert st.inner_node_bytes == 64
+            assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+            img, rst = r.render(p)
+            assert_same_image(img, ref, f"compressed nodes, driver {impl}")
+            assert rst.rays == ost.rays
+        finally:
+            r.close()

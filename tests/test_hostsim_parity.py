@@ -133,3 +133,40 @@ def test_max_depth_and_one_spp():
         assert np.array_equal(a, b)
         assert sa.max_bounces <= md - 1 and rays[2] == sa.rays_indirect
     assert O.render(s.flat, T.make_params(32, 32, 1, 5, max_depth=1))[1].rays_indirect == 0
+
+
+@pytest.mark.parametrize("name", ["veach-mis", "staircase"])
+def test_compressed_nodes_give_the_same_hits_and_image(name):
+    """TRT_NODE_KIND=1 (trt_path.h CNode): quantised conservative boxes + acceptance by the leaf's exact box reach exactly the
+    reference's leaves — hits, barycentrics, image and ray counts identical to the oracle, also on degenerate rays."""
+    s = get_scene(name, 64, 36)
+    assert H.compressible(s.flat)
+    old = H.set_node_kind(1)
+    try:
+        org, dirs = raygen.adversarial_rays(s, 20000)
+        lo, hi = raygen.scene_bounds(s)
+        o2, d2 = raygen.random_rays(20000, lo - 5, hi + 5, seed=4)
+        org, dirs = np.vstack([org, o2]), np.vstack([dirs, d2])
+        t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+        t1, tri1, uv1, cnt1 = H.trace(s.flat, org, dirs)
+        assert np.array_equal(t0, t1) and np.array_equal(tri0, tri1) and np.array_equal(uv0, uv1)
+        H.set_node_kind(0)
+        _, _, _, cnt0 = H.trace(s.flat, org, dirs)
+        assert cnt0[0] <= cnt1[0] <= 1.05 * cnt0[0]  # looser boxes: a few per cent more visits, never fewer
+        H.set_node_kind(1)
+        p = T.make_params(64, 36, 4, 11)
+        img, rays = H.render(s.flat, p)
+        ref, st = O.render(s.flat, p)
+        assert np.array_equal(img, ref) and rays == [st.rays_camera, st.rays_shadow, st.rays_indirect]
+    finally:
+        H.set_node_kind(old)
+
+
+def test_foreign_tree_is_not_compressed():
+    """A tree whose boxes are not nested (a child's box sticks out of its parent's) cannot use the leaf-box argument."""
+    import scene_util as SU
+    s = T.Scene.named("staircase", 64, 36)
+    assert H.compressible(s.flat)
+    assert SU.shrink_some_boxes(s, 50) > 0
+    assert not H.compressible(s.flat)
+    s.close()

@@ -404,10 +404,11 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         const WideTree wide = greedy ? collapseBvhGreedy(s->nodes, s->n_nodes) : collapseBvh(s->nodes, s->n_nodes);
         h->sc.n_wnodes = (uint32_t)wide.nodes.size();
         h->depth = wide.stack_need + 1;
-        // 64-B compressed nodes + exact leaf boxes (nested trees only: every builder's is) where they measured faster: the
-        // scenes whose node array does not fit the L2s (half the lines to fetch); on L2-resident scenes the 36 extra VALU
-        // instructions of a visit cost more than the three loads they save.  TRT_NODE_KIND=0/1 forces either.
-        bool want_c = h->trace_impl != 0 && s->n_tris > 4000000u;
+        // 64-B compressed nodes + exact leaf boxes (nested trees only: every builder's is) are an OPTION, TRT_NODE_KIND=1: four
+        // loads per visit instead of seven, bit-identical results, but the 36 VALU instructions that rebuild the boxes cost
+        // more than the loads save on every scene but the 1 M-triangle soup (measured): the traversal kernels
+        // are bound by instruction issue, not by the texture-address rate.
+        bool want_c = false;
         if (const char* e = std::getenv("TRT_NODE_KIND")) want_c = h->trace_impl != 0 && std::atoi(e) != 0;
         CompressedTree comp;
         if (want_c) comp = compressWide(wide, s->nodes, s->n_nodes, s->n_tris);
@@ -488,6 +489,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     std::memset(h->pinned_counts, 0, 2 * (2 * COUNT_ROW + 16) * sizeof(uint32_t));  // sequence words start at 0; the first one asked for is 1
     if (const char* e = std::getenv("TRT_SLOTS")) h->n_slots = std::atoi(e) >= 2 ? 2 : 1;
     if (const char* e = std::getenv("TRT_TEST_FAIL_AT_BOUNCE")) h->fail_at_bounce = std::atoi(e);
+
     *out = h.release();
     return TRT_OK;
 }

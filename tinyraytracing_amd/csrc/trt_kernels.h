@@ -204,7 +204,7 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
 constexpr int TRT_PEND_SLOTS = 4;
 // The walk itself for the rays the active lanes of a wave hold (`valid`: this lane has one).  best_t comes in as the
 // bound of the search (TRT_INF, or an occlusion range) and goes out with best_tri / best_flags as the closest hit.
-template <bool COUNT>
+template <bool COUNT, int STRIDE = TRT_TRACE_BLOCK>
 __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool valid, f4* __restrict__ my_pend, float& best_t, int32_t& best_tri,
                                             uint32_t& best_flags, uint32_t& n_inner, uint32_t& n_tri)
 {
@@ -216,7 +216,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
     auto flush = [&]() {
         for (uint32_t s = 0; __ballot(s < n_pend) != 0ull; ++s) {
             if (s < n_pend) {
-                const f4 e = my_pend[s * TRT_TRACE_BLOCK];
+                const f4 e = my_pend[s * STRIDE];
                 const float t = e.x / e.y;
                 if (!(t < TRT_T_MIN)) {  // bvh.cpp:189
                     const int32_t j = (int32_t)f2u(e.z);
@@ -262,7 +262,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
                 const bool cand = triCandidate(T, o, d, tn, un, vn, det) && hc[c];
                 if (__ballot(cand && n_pend == (uint32_t)TRT_PEND_SLOTS) != 0ull) flush();  // a full queue: empty all of them first
                 if (cand) {
-                    my_pend[n_pend * TRT_TRACE_BLOCK] = mk4(tn, det, u2f(first + k), u2f(ref));
+                    my_pend[n_pend * STRIDE] = mk4(tn, det, u2f(first + k), u2f(ref));
                     n_pend++;
                 }
             }
