@@ -317,10 +317,10 @@ def test_tiny_tree_with_children_before_parents(scene_factory):
 
 
 def test_failure_mid_render_leaves_the_handle_usable(monkeypatch):
-    """an error return with kernels in flight (here an injected one, after bounce 1 has been issued on
-    both overlapped passes) must drain the streams; the same handle then renders the oracle's image."""
+    """an error return with kernels in flight (here an injected one, right after bounce 0 of the first
+    of two overlapped passes has been issued) must drain the streams; the same handle then renders the oracle's image."""
     s = get_scene("veach-mis", 96, 54)
-    monkeypatch.setenv("TRT_TEST_FAIL_AT_BOUNCE", "1")
+    monkeypatch.setenv("TRT_TEST_FAIL_AT_BOUNCE", "0")
     r = T.Renderer(s, 0)
     monkeypatch.delenv("TRT_TEST_FAIL_AT_BOUNCE")
     p = T.make_params(96, 54, 8, 0x5EED0002, flags=T.TRT_FLAG_OVERLAP)
