@@ -93,9 +93,9 @@ def test_trace_soup_deep_bvh(renderer_factory):
     assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
 
 
-@pytest.mark.parametrize("impl", ["1", "2", "3"])
+@pytest.mark.parametrize("impl", ["1", "2", "3", "4"])
 def test_every_wave_driver_gives_the_same_image(impl, monkeypatch):
-    """TRT_TRACE_IMPL forces the static / while-while / scheduler traversal driver (trt_kernels.h); the library
+    """TRT_TRACE_IMPL forces the static / while-while / scheduler / speculative-scheduler traversal driver (trt_kernels.h); the library
     picks one per scene, and all of them must reproduce the oracle."""
     monkeypatch.setenv("TRT_TRACE_IMPL", impl)
     s = get_scene("veach-mis", 96, 54)
@@ -489,7 +489,7 @@ def test_fixed_nee_image_matches_oracle(name, w, h, spp, renderer_factory):
     assert np.array_equal(img, ref)
 
 
-@pytest.mark.parametrize("impl", ["1", "2", "3"])
+@pytest.mark.parametrize("impl", ["1", "2", "3", "4"])
 def test_fixed_nee_on_every_wave_driver(impl, monkeypatch):
     """The occlusion test (stop at the first hit in front of the light sample) in the static, while-while and
     scheduler drivers; 160 x 90 x 32 spp keeps the regular kernels (not only k_tail) busy."""
@@ -620,7 +620,7 @@ def test_compressed_nodes_on_the_gpu(monkeypatch):
     p = T.make_params(96, 54, 8, T.SEED_STAIRCASE)
     ref, ost = O.render(s.flat, p)
     monkeypatch.setenv("TRT_NODE_KIND", "1")
-    for impl in ("1", "2", "3"):
+    for impl in ("1", "2", "3", "4"):
         monkeypatch.setenv("TRT_TRACE_IMPL", impl)
         r = T.Renderer(s, 0)
         try:

@@ -289,6 +289,7 @@ struct Timer {
     do {                                                                     \
         if (h->trace_impl == 1) TRT_BY_DEPTH(LAUNCH, 1, NK);                 \
         else if (h->trace_impl == 2) TRT_BY_DEPTH(LAUNCH, 2, NK);            \
+        else if (h->trace_impl == 4) TRT_BY_DEPTH(LAUNCH, 4, NK);            \
         else TRT_BY_DEPTH(LAUNCH, 3, NK);                                    \
     } while (0)
 
@@ -382,7 +383,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
             if (!(c & TRT_LEAF_BIT) && c <= n) tiny = false;
     }
     h->trace_impl = tiny ? 0 : (depth <= 8 ? 1 : 3);
-    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { const int v = std::atoi(e); if (v >= (tiny ? 0 : 1) && v <= 3) h->trace_impl = v; }
+    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { const int v = std::atoi(e); if (v >= (tiny ? 0 : 1) && v <= 4) h->trace_impl = v; }
 
     {   // 48-B intersection records and 64-B shading records
         std::vector<TriIsect> isect(s->n_tris);

@@ -366,6 +366,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
     uint32_t best_flags = 0;
     // IMPL 3: fold state of the leaf the lane is in (interactBVHNode's local `res`, bvh.cpp:213)
     uint32_t lk = 0;  // next triangle of the leaf, relative to its first
+    uint32_t post = TRT_REF_IDLE;  // IMPL 4: a leaf parked for a later leaf step (TRT_REF_IDLE = none)
     float lt = TRT_INF;
     int32_t li = -1;
     uint32_t lflags = 0;
@@ -397,6 +398,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                     sp = 0;
                     cur = 0u;  // nodes[0] is always an inner node
                     lk = 0; lt = TRT_INF; li = -1;
+                    post = TRT_REF_IDLE;
                 }
                 const uint32_t taken = (uint32_t)__popcll(m_free);
                 next = (end - next) < taken ? end : next + taken;
@@ -454,6 +456,66 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                 else cur = TRT_REF_DONE;
             }
             if (COUNT && lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_tri++;
+        }
+        } else if constexpr (IMPL == 4) {
+        // ---- scheduler with a postponed leaf (speculative traversal): a lane that arrives at a leaf parks it in `post`
+        // and goes on with the next node from its stack, so node steps keep more lanes busy; leaf steps then serve every
+        // lane that has a leaf pending — the parked one first, then the one it stands on.  The price is a later best_t
+        // (a few nodes more are visited); the result cannot change: which leaves and nodes are looked at, and in what
+        // order, never enters the hit (traceClosest's tie rules are order independent, culling is by strict distance).
+        if ((cur & TRT_LEAF_BIT) && cur < TRT_REF_DONE && post == TRT_REF_IDLE && sp != 0) { post = cur; cur = stk.pop(--sp); }
+        const bool is_inner = !(cur & TRT_LEAF_BIT);
+        const bool cur_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
+        const bool leaf_work = cur_leaf || post != TRT_REF_IDLE;
+        const unsigned long long m_in = __ballot(is_inner), m_blk = __ballot(cur_leaf), m_lw = __ballot(leaf_work);
+        bool adv = false;
+        if (sc.sched_in_w * (uint32_t)__popcll(m_in) >= sc.sched_lf_w * (uint32_t)__popcll(m_blk)) {
+            if (is_inner) {
+                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
+                if (!innerStep<NK>(sc, cur, sp, stk, o, inv, best_t)) adv = true;
+            }
+        } else {
+            if (leaf_work) {
+                const bool from_post = post != TRT_REF_IDLE;
+                const uint32_t lref = from_post ? post : cur;
+                const uint32_t first = TRT_LEAF_FIRST(lref), count = TRT_LEAF_COUNT(lref);
+                if (lk < count) {
+                    const uint32_t i = first + lk;
+                    const TriIsect T = sc.tri_isect[i];
+                    if (COUNT) { pr.n_tri++; if (lane == (uint32_t)__ffsll((long long)m_lw) - 1u) pr.wave_tri++; }
+                    float t, un, vn, det;
+                    if (triTest(T, o, d, t, un, vn, det)) {
+                        const uint32_t fl = f2u(T.c.z);
+                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lflags = fl; }
+                    }
+                    lk++;
+                }
+                if (lk >= count) {  // leaf done: merge its winner
+                    if (li >= 0) {
+                        bool take = lt < best_t;
+                        if (lt == best_t && best_tri >= 0) {
+                            const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
+                            take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
+                        }
+                        if (NK == 1 && take) take = leafBoxPasses(sc, first, o, inv);
+                        if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
+                    }
+                    lk = 0; lt = TRT_INF; li = -1;
+                    if (from_post) {
+                        post = TRT_REF_IDLE;  // the lane goes on with the node it stands on
+                        if (any && best_tri >= 0) { cur = TRT_REF_DONE; }
+                    } else {
+                        adv = true;
+                    }
+                }
+            }
+        }
+        if (adv) {  // done with the node the lane stands on (post is empty here, or the node was an inner one)
+            if (any && best_tri >= 0) { cur = TRT_REF_DONE; post = TRT_REF_IDLE; }
+            else if (sp != 0) cur = stk.pop(--sp);
+            else if (post != TRT_REF_IDLE) { cur = post; post = TRT_REF_IDLE; }  // only the parked leaf is left
+            else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }
+            else cur = TRT_REF_DONE;
         }
         } else {
         const bool is_inner = !(cur & TRT_LEAF_BIT);
