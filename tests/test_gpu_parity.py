@@ -472,6 +472,17 @@ def test_cli_progressive_render_resumes_from_its_checkpoint(tmp_path):
     assert open(b, "rb").read() == open(a, "rb").read()
     bad = subprocess.run(base[:-1] + ["78", "--out", b, "--checkpoint", ck], capture_output=True, timeout=300)
     assert bad.returncode != 0 and b"another render" in bad.stderr
+    # the sums of one estimator / one scene must not be continued with another
+    bad = subprocess.run(base + ["--out", b, "--checkpoint", ck, "--fixed-nee"], capture_output=True, timeout=300)
+    assert bad.returncode != 0 and b"another estimator" in bad.stderr
+    dv = os.path.join(os.path.dirname(T.__file__), "..", "scenes", "veach-mis")
+    other = [exe, dv, os.path.join(dv, "veach-mis.mtl"), os.path.join(dv, "veach-mis.xml"), os.path.join(dv, "veach-mis.obj"), "16", "--width", "96", "--height", "54", "--seed", "77"]
+    bad = subprocess.run(other + ["--out", b, "--checkpoint", ck], capture_output=True, timeout=300)
+    assert bad.returncode != 0 and b"another scene" in bad.stderr
+    # a run that stops early says that its picture is not normalised yet
+    ck2 = str(tmp_path / "c.acc")
+    part = subprocess.run(base + ["--out", b, "--every", "4", "--checkpoint", ck2, "--stop-after", "4"], capture_output=True, timeout=300)
+    assert part.returncode == 0 and b"stopped after 4 of 16 samples" in part.stderr
     s = get_scene("back", 96, 54)
     img, _ = T.Renderer(s, 0).render(T.make_params(96, 54, 16, 77))
     T.imshow(img, str(tmp_path / "c.png"))

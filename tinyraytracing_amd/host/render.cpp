@@ -9,13 +9,34 @@
 namespace trt {
 
 namespace {
-const char CKPT_MAGIC[8] = {'T', 'R', 'T', 'A', 'C', 'C', '1', 0};
+const char CKPT_MAGIC[8] = {'T', 'R', 'T', 'A', 'C', 'C', '2', 0};
 struct CkptHead {
     char magic[8];
     int32_t width, height, spp, samples_done, max_depth;
     uint32_t seed;
+    uint32_t flags, n_triangles, n_nodes, reserved;
+    uint64_t scene_hash;
     uint64_t n_doubles;
 };
+uint64_t fnv1a(const void* data, size_t bytes, uint64_t h)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+// what the accumulated sums depend on besides the render parameters: geometry, materials, lights, camera
+uint64_t sceneHash(const trt_scene* s)
+{
+    uint64_t h = 1469598103934665603ull;
+    h = fnv1a(s->tri_v, (size_t)s->n_tris * 9 * sizeof(float), h);
+    h = fnv1a(s->tri_vn, (size_t)s->n_tris * 9 * sizeof(float), h);
+    h = fnv1a(s->tri_vt, (size_t)s->n_tris * 6 * sizeof(float), h);
+    h = fnv1a(s->tri_mat, (size_t)s->n_tris * sizeof(int32_t), h);
+    h = fnv1a(s->materials, (size_t)s->n_materials * sizeof(trt_material), h);
+    h = fnv1a(s->lights, (size_t)s->n_lights * sizeof(trt_light), h);
+    h = fnv1a(&s->camera, sizeof(trt_camera), h);
+    return h;
+}
 }  // namespace
 
 bool readCheckpoint(const std::string& path, Checkpoint& head, std::vector<double>& accum)
@@ -32,6 +53,7 @@ bool readCheckpoint(const std::string& path, Checkpoint& head, std::vector<doubl
     std::fclose(f);
     if (!ok) throw std::runtime_error("checkpoint " + path + ": not an accumulator file of this program");
     head.width = h.width; head.height = h.height; head.spp = h.spp; head.samples_done = h.samples_done; head.max_depth = h.max_depth; head.seed = h.seed;
+    head.flags = h.flags; head.n_triangles = h.n_triangles; head.n_nodes = h.n_nodes; head.scene_hash = h.scene_hash;
     return true;
 }
 
@@ -43,6 +65,7 @@ void writeCheckpoint(const std::string& path, const Checkpoint& head, const std:
     CkptHead h;
     std::memcpy(h.magic, CKPT_MAGIC, 8);
     h.width = head.width; h.height = head.height; h.spp = head.spp; h.samples_done = head.samples_done; h.max_depth = head.max_depth; h.seed = head.seed;
+    h.flags = head.flags; h.n_triangles = head.n_triangles; h.n_nodes = head.n_nodes; h.reserved = 0; h.scene_hash = head.scene_hash;
     h.n_doubles = accum.size();
     const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(accum.data(), sizeof(double), accum.size(), f) == accum.size();
     if (std::fclose(f) != 0 || !ok) throw std::runtime_error("cannot write " + tmp);
@@ -91,12 +114,17 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
         // progressive: the accumulator lives on the host between calls (and in the checkpoint file)
         std::vector<double> accum(out.size(), 0.0);
         int done = 0;
+        const uint32_t est_flags = p.flags & (TRT_FLAG_FIXED_NEE | TRT_FLAG_FIXED_PIXELS);
+        const uint64_t scene_hash = opts.checkpoint.empty() ? 0ull : sceneHash(flat.c_scene());
         try {
             Checkpoint ck;
             std::vector<double> saved;
             if (!opts.checkpoint.empty() && readCheckpoint(opts.checkpoint, ck, saved)) {
                 if (ck.width != p.width || ck.height != p.height || ck.spp != p.spp || ck.seed != p.seed || ck.max_depth != p.max_depth)
                     throw std::runtime_error("checkpoint " + opts.checkpoint + " belongs to another render (size, spp, seed or max depth differ)");
+                if (ck.flags != est_flags) throw std::runtime_error("checkpoint " + opts.checkpoint + " was accumulated with another estimator (--fixed-nee / --fixed-pixels differ)");
+                if (ck.n_triangles != flat.c_scene()->n_tris || ck.n_nodes != flat.c_scene()->n_nodes || ck.scene_hash != scene_hash)
+                    throw std::runtime_error("checkpoint " + opts.checkpoint + " belongs to another scene (triangles, BVH or scene hash differ)");
                 accum.swap(saved);
                 done = ck.samples_done;
             }
@@ -119,6 +147,7 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
                 if (!opts.checkpoint.empty()) {
                     Checkpoint w;
                     w.width = p.width; w.height = p.height; w.spp = p.spp; w.samples_done = done; w.max_depth = p.max_depth; w.seed = p.seed;
+                    w.flags = est_flags; w.n_triangles = flat.c_scene()->n_tris; w.n_nodes = flat.c_scene()->n_nodes; w.scene_hash = scene_hash;
                     writeCheckpoint(opts.checkpoint, w, accum);
                 }
                 if (opts.on_progress) opts.on_progress(done, out.data());
@@ -127,6 +156,8 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
             trt_destroy(h);
             throw;
         }
+        if (rc == TRT_OK && done < p.spp)
+            std::fprintf(stderr, "warning: stopped after %d of %d samples: the image holds the sum of %d samples divided by %d (resume from the checkpoint to finish it)\n", done, p.spp, done, p.spp);
     }
     trt_destroy(h);
     if (rc != TRT_OK) throw std::runtime_error("trt_render: " + msg);

@@ -40,6 +40,9 @@ struct RenderOpts {
 struct Checkpoint {
     int32_t width = 0, height = 0, spp = 0, samples_done = 0, max_depth = 0;
     uint32_t seed = 0;
+    uint32_t flags = 0;           // the estimator the sums belong to: TRT_FLAG_FIXED_NEE / TRT_FLAG_FIXED_PIXELS
+    uint32_t n_triangles = 0, n_nodes = 0;
+    uint64_t scene_hash = 0;      // FNV-1a over the flattened triangles (post-BVH order), materials, lights and the camera
 };
 bool readCheckpoint(const std::string& path, Checkpoint& head, std::vector<double>& accum);   // false: no such file
 void writeCheckpoint(const std::string& path, const Checkpoint& head, const std::vector<double>& accum);
