@@ -151,3 +151,29 @@ def test_closest_hits_of_the_two_formulations_on_the_scenes():
         assert np.all(np.abs(tf[hit] - tl[hit]) <= 2e-5 * np.maximum(tl[hit], 1.0)), name
         duv = np.abs(uvf[hit] - uvl[hit]).max(axis=1)  # small triangles far from the origin: P = S + d t carries ~1e-4 of noise
         assert np.percentile(duv, 99) < 2e-4 and duv.max() < 2e-2, (name, np.percentile(duv, 99), duv.max())
+
+
+@pytest.mark.gpu
+def test_config2_hip_image_within_the_stated_tolerance_of_the_reference_arithmetic(renderer_factory):
+    """BASELINE config 2 at full size — back, 1024 x 1024, 256 spp, seeded RNG — rendered by the HIP path through the C-ABI
+    and compared with the reference's own arithmetic (ORACLE_MODE_LITERAL on the host cores): THE stated fp32 per-pixel L2
+    tolerance of the north star.  tau(pixel) = ||g - c||_2 / (1 + ||c||_2) over linear RGB.
+    Measured (profiles/r02_tolerance_back_1024x1024_256spp.json): 99.37 % of pixels within 1e-2 (p99 8.8e-3), 8x8-block means
+    p99 6.3e-3, mean radiance 1.7e-4 relative.  The maximum is firefly-dominated (one 1/r^2 sample next to the light that only
+    one of the two formulations' paths takes) and is not bounded."""
+    s = get_scene("back", 1024, 1024)
+    p = T.make_params(1024, 1024, 256, T.SEED_BACK)
+    img, st = renderer_factory(s).render(p)
+    lit, sl = O.render_literal(s.flat, p)
+    r = _tau(img, lit)
+    g, c = img.astype(np.float64), lit.astype(np.float64)
+    gb = g.reshape(128, 8, 128, 8, 3).mean(axis=(1, 3))
+    cb = c.reshape(128, 8, 128, 8, 3).mean(axis=(1, 3))
+    rb = np.sqrt(((gb - cb) ** 2).sum(axis=2)) / (1.0 + np.sqrt((cb ** 2).sum(axis=2)))
+    frac = float((r <= 1e-2).mean())
+    mean_rel = float(abs(g.mean() - c.mean()) / c.mean())
+    print(f"config 2: {frac * 100:.2f} % of pixels within tau = 1e-2, p99 {np.percentile(r, 99):.2e}, blocks p99 {np.percentile(rb, 99):.2e}, mean {mean_rel:.2e}")
+    assert frac >= 0.99, frac
+    assert np.percentile(rb, 99) <= 1e-2
+    assert mean_rel <= 5e-4
+    assert st.rays_camera == sl.rays_camera and abs(st.rays_indirect - sl.rays_indirect) <= 1e-3 * sl.rays_indirect
