@@ -20,7 +20,7 @@ HOST_HDR := $(wildcard $(PKG)/host/*.h) include/trt.h include/trt_host.h include
 HIP_SRC := $(PKG)/csrc/trt_api.hip
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h
 
-.PHONY: all host hip oracle cli hostsim variants clean
+.PHONY: all host hip oracle cli hostsim variants probe clean
 all: host hip oracle hostsim cli
 
 host: $(OUT)/libtrt_host.so
@@ -55,3 +55,8 @@ variants: $(HIP_SRC) $(HIP_HDR)
 clean:
 	rm -rf $(OUT) tests/hostsim/libhostsim.so
 	$(MAKE) -C oracle clean
+
+# chip-ceiling probe + TCC counter calibration workload (tools/calibrate_counters.sh runs it on the GPU box)
+probe: tools/gather_probe
+tools/gather_probe: tools/gather_probe.hip
+	$(HIPCC) -O3 --offload-arch=gfx950 -o $@ tools/gather_probe.hip

@@ -46,6 +46,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -319,6 +320,10 @@ struct Vertex {
     const trt_material* m;
 };
 
+// EXPERIMENT (tools/rank_ref_png.py --variants): estimator variants tried against the reference's `back` snapshots, which predate
+// the committed indirect term.  Never set by tests of the parity path.
+static bool g_experiment_no_rr_div = false;
+
 struct PathTracer {
     const SceneView& sv;
     Counters& cnt;
@@ -441,7 +446,7 @@ struct PathTracer {
                         type_out = type;
                         if (type != TRT_RAY_INVALID) {
                             const V3 w = (type == TRT_RAY_TRANSMISSION) ? ld(vx.m->Tr) : vx.Kd;  // Q8
-                            beta = (beta * w) / TRT_P_RR;
+                            beta = g_experiment_no_rr_div ? beta * w : (beta * w) / TRT_P_RR;
                             o = vx.P;  // Q6: no offset
                             d = nd;
                             prev_type = type;
@@ -545,6 +550,7 @@ extern "C" {
 
 int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats, int threads, int mode)
 {
+    g_experiment_no_rr_div = std::getenv("ORACLE_EXPERIMENT_NO_RR_DIV") != nullptr;
     if (int e = checkParams(scene, p)) return e;
     if (!out_rgb) return TRT_EINVAL;
     const SceneView sv(scene);

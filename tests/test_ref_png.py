@@ -19,7 +19,8 @@ Which snapshot belongs to the committed code was established by ranking all of t
                           -radiance / -avg / -num are named after them); kept as the negative control.
   test/image10.png, test/image10-0.png (`back`)   geometry and pixel grid exact (first/last lit row and column), block
                           structure correlated 0.987, but 11-22 % darker than the committed code renders this scene, the
-                          ceiling (indirect light only) most: older revisions of the indirect term.  They pin Q1/Q2 and the
+                          ceiling (indirect light only) most: older revisions of the indirect term (without the 1 / P_RR of
+                          pathTracing.cpp:84 the distance halves: test_back_snapshots_predate_...).  They pin Q1/Q2 and the
                           geometry, not the brightness.
 
 Tolerances are stated per fixture below; the CPU tests use the oracle at a few spp, the -m gpu tests the HIP render
@@ -125,6 +126,26 @@ def test_back_snapshots_pin_pixel_grid_and_geometry(fixture):
     med, p90, corr = _compare(img, png)
     assert corr >= 0.98, corr            # measured 0.987: same silhouettes block for block
     assert med <= 0.30, med              # measured 0.11 (image10-0) / 0.22 (image10): an older, darker indirect term
+
+
+def test_back_snapshots_predate_the_russian_roulette_compensation(monkeypatch):
+    """Why the `back` snapshots are darker than the committed code renders the scene: an estimator WITHOUT the 1 / P_RR of
+    pathTracing.cpp:84 (an oracle experiment switch, never part of the parity path) halves the distance to both of them
+    (median block error 11-22 % -> 5.6 %, correlation 0.987 -> 0.995) — they were written by an earlier revision of the indirect
+    term.  The committed code's division is what veach-mis/image10.png and staircase/image10.png confirm to 1 % / 6 %."""
+    s = get_scene("back", 1024, 1024)
+    p = T.make_params(1024, 1024, 8, SEEDS["back"])
+    committed = _oracle_render("back", 8)
+    monkeypatch.setenv("ORACLE_EXPERIMENT_NO_RR_DIV", "1")
+    variant = O.render(s.flat, p)[0]
+    monkeypatch.delenv("ORACLE_EXPERIMENT_NO_RR_DIV")
+    assert np.array_equal(O.render(s.flat, T.make_params(1024, 1024, 1, 3, tile=(500, 500, 516, 508)))[0],
+                          O.render(s.flat, T.make_params(1024, 1024, 1, 3, tile=(500, 500, 516, 508)))[0])  # the switch is off again
+    for fixture in ("back_image10.png", "back_image10-0.png"):
+        png = _png(fixture)
+        med_c, _, corr_c = _compare(committed, png)
+        med_v, _, corr_v = _compare(variant, png)
+        assert med_v < 0.08 and corr_v > 0.993 and med_v < 0.7 * med_c and corr_v > corr_c, (fixture, med_c, med_v, corr_c, corr_v)
 
 
 # ------------------------------------------------------------------------------------------------ HIP path
