@@ -1,0 +1,41 @@
+#!/bin/bash
+# Fills BASELINE.md §3: one bench.py line per config on ONE GPU (the multi-GPU columns come from the driver's 8-GPU node) plus the
+# pinned one-socket CPU baseline of each scene.  Output: gpurun_out/baseline/*.json and a markdown table on stdout.
+root=${GRAFT_REPO_ROOT:-/root/repo}
+cd $root
+out=gpurun_out/baseline; mkdir -p $out
+python bench.py --width 1024 --height 1024 --no-extra > $out/c2.json 2> $out/c2.err; echo "c2 done" >&2
+python bench.py --scene soup --spp 64 --steps 2 > $out/c3.json 2> $out/c3.err; echo "c3 done" >&2
+python bench.py --scene staircase --spp 1024 --steps 1 > $out/c4.json 2> $out/c4.err; echo "c4 done" >&2
+python bench.py --scene blob --tris 10000000 --width 3840 --height 2160 --spp 4096 --steps 1 > $out/c5.json 2> $out/c5.err; echo "c5 done" >&2
+python bench.py --no-extra > $out/h_back.json 2> $out/h_back.err
+python bench.py --scene veach-mis --steps 2 > $out/h_veach.json 2> $out/h_veach.err
+python bench.py --scene staircase --steps 1 > $out/h_stair.json 2> $out/h_stair.err; echo "headline done" >&2
+python tools/cpu_baseline.py --scene back --width 256 --height 256 --spp 4 --seconds 1 > $out/c1.json 2> $out/c1.err
+python - <<'PY'
+import json, os
+out = "gpurun_out/baseline"
+def load(n):
+    try:
+        return json.loads(open(f"{out}/{n}.json").read().strip().splitlines()[-1])
+    except Exception as e:
+        return None
+rows = [("2 back 1024² 256 spp", "c2"), ("3 soup-1M 1920×1080 64 spp", "c3"), ("4 staircase 1920×1080 1024 spp (on 1 GPU)", "c4"),
+        ("5 blob-10M 3840×2160 4096 spp (on 1 GPU)", "c5"), ("headline back 1080p 256 spp", "h_back"), ("headline veach-mis 1080p 256 spp", "h_veach"),
+        ("headline staircase 1080p 256 spp", "h_stair")]
+c1 = load("c1")
+print("| Config | GPUs | Rays traced / step | Time (ms) | Mrays/s | Algorithmic bytes / step | Achieved GB/s (all kernels) | % of 8.0 TB/s | % of 6.29 TB/s | dominant kernel: GB/s (frac) | CPU Mrays/s (cores) | GPU/CPU |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+if c1:
+    print(f"| 1 back 256² 4 spp (CPU only) | 0 | {c1['sample']} | — | {c1['value']} | — | — | — | — | — | {c1['value']} ({c1['cores']}) | — |")
+for label, n in rows:
+    d = load(n)
+    if not d:
+        print(f"| {label} | 1 | failed | | | | | | | | | |")
+        continue
+    g = d.get("hbm_algorithmic_GBps_rank0") or 0.0
+    alg = g * 1e9 * d["device_render_ms_per_step_rank0"] * 1e-3
+    cb = d.get("cpu_baseline") or {}
+    print(f"| {label} | 1 | {d['rays_per_step']:,} | {d['ms_per_step']} | {d['value']} | {alg / 1e9:.1f} GB | {g:.0f} | {g / 80:.0f} % | {g / 62.9:.0f} % | "
+          f"{d['roofline']['kernel']} {d['roofline']['achieved']:.0f} ({d['roofline']['frac']}) | {cb.get('value')} ({cb.get('cores')}) | {d.get('gpu_over_cpu')}× |")
+PY

@@ -113,6 +113,32 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t iters, float* __restrict_
     if (s == 123.456f) sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// 32-bit integer multiplies (the counter RNG of trt_prims.h spends five per draw) and IEEE divisions (43 per path vertex in k_shade)
+__global__ __launch_bounds__(256) void k_imul(uint32_t iters, float* __restrict__ sink)
+{
+    uint32_t a0 = threadIdx.x | 1u, a1 = a0 + 2, a2 = a0 + 4, a3 = a0 + 6, a4 = a0 + 8, a5 = a0 + 10, a6 = a0 + 12, a7 = a0 + 14;
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a0 *= 0x7feb352du; a1 *= 0x846ca68bu; a2 *= 0x7feb352du; a3 *= 0x846ca68bu;
+            a4 *= 0x7feb352du; a5 *= 0x846ca68bu; a6 *= 0x7feb352du; a7 *= 0x846ca68bu;
+        }
+    }
+    const uint32_t s = ((a0 ^ a1) ^ (a2 ^ a3)) ^ ((a4 ^ a5) ^ (a6 ^ a7));
+    if (s == 123456u) sink[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;
+}
+__global__ __launch_bounds__(256) void k_fdiv(uint32_t iters, float* __restrict__ sink)
+{
+    float a0 = 1.0f + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    const float d = 1.0000001f + 1e-7f * threadIdx.x;
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a0 = a0 / d; a1 = a1 / d; a2 = a2 / d; a3 = a3 / d; }
+    }
+    const float s = (a0 + a1) + (a2 + a3);
+    if (s == 123.456f) sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 static double timeIt(hipEvent_t e0, hipEvent_t e1)
 {
     float ms = 0.f;
@@ -218,6 +244,22 @@ int main(int argc, char** argv)
             const double wave_instr = (double)cus * bpc * 4 * iters * 64.0;
             std::printf("%-52s %8.3f ms  %6.3f wave-instr/clk/SIMD (nominal clock)  %7.1f TFLOP/s\n", name, ms, wave_instr / (ms * 1e-3 * clk) / (cus * 4.0),
                         wave_instr * 64 * 2 / ms / 1e9);
+        }
+    }
+    for (int which = 0; which < 2; ++which) {
+        const char* name = which == 0 ? "valu v_mul_lo_u32 waves/SIMD=8" : "valu IEEE fp32 division waves/SIMD=8";
+        if (only[0] && !std::strstr(name, only)) continue;
+        const uint32_t iters = which == 0 ? 2048 : 512;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            if (which == 0) hipLaunchKernelGGL(k_imul, dim3((uint32_t)cus * 8), dim3(256), 0, 0, iters, sink);
+            else hipLaunchKernelGGL(k_fdiv, dim3((uint32_t)cus * 8), dim3(256), 0, 0, iters, sink);
+            CK(hipEventRecord(e1));
+            const double ms = timeIt(e0, e1);
+            if (rep == 0) continue;
+            const double ops = (double)cus * 8 * 4 * iters * (which == 0 ? 64.0 : 32.0);  // wave-level operations
+            std::printf("%-52s %8.3f ms  %6.3f wave-ops/clk/SIMD (nominal clock) = one per %.1f clocks\n", name, ms, ops / (ms * 1e-3 * clk) / (cus * 4.0),
+                        (ms * 1e-3 * clk) * (cus * 4.0) / ops);
         }
     }
     CK(hipDeviceSynchronize());
