@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Randomised parity soak: random tiles / row interleaves / spp / seeds / flags / depth caps / memory budgets of the three cg22
+scenes (and a 50 k-triangle soup) rendered by the HIP path through the C-ABI and by the oracle; every image and every ray count
+must be identical.  usage: tools/fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+import tinyraytracing_amd as T  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    sizes = {"back": (257, 131), "veach-mis": (320, 180), "staircase": (192, 108), "soup": (160, 90)}
+    scenes, renderers = {}, {}
+    for name, (w, h) in sizes.items():
+        scenes[name] = T.Scene.named(name, w, h, **({"n": 50000} if name == "soup" else {}))
+        renderers[name] = T.Renderer(scenes[name], 0)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < budget:
+        name = list(sizes)[int(rng.integers(0, len(sizes)))]
+        w, h = sizes[name]
+        x0 = int(rng.integers(0, w - 1)); x1 = int(rng.integers(x0 + 1, min(w, x0 + 40) + 1))
+        y0 = int(rng.integers(0, h - 1)); y1 = int(rng.integers(y0 + 1, min(h, y0 + 24) + 1))
+        spp = int(rng.choice([1, 2, 3, 5, 8, 17, 33]))
+        seed = int(rng.integers(0, 2 ** 32))
+        flags = 0
+        if rng.random() < 0.3: flags |= T.TRT_FLAG_FIXED_NEE
+        if rng.random() < 0.2: flags |= T.TRT_FLAG_FIXED_PIXELS
+        if rng.random() < 0.4: flags |= T.TRT_FLAG_OVERLAP
+        if rng.random() < 0.3: flags |= T.TRT_FLAG_COUNT
+        md = int(rng.choice([0, 0, 0, 1, 2, 5]))
+        rows = None
+        if rng.random() < 0.4:
+            rb = int(rng.choice([1, 2, 8])); rm = int(rng.choice([2, 3, 8])); rows = (rb, rm, int(rng.integers(0, rm)))
+        npix = (x1 - x0) * (y1 - y0)
+        budget_b = 0 if rng.random() < 0.6 else int(npix * (2 * 48 + 32 + 48 * 8) * int(rng.choice([1, 2, 3])) + 4096 * 16 * 16)
+        p = T.make_params(w, h, spp, seed, tile=(x0, y0, x1, y1), rows=rows, max_depth=md, flags=flags, mem_budget=budget_b)
+        if not T.rows_selected(p):
+            continue
+        try:
+            img, st = renderers[name].render(p)
+        except T.TrtError as e:
+            if "mem_budget too small" in str(e):
+                continue
+            raise
+        ref, ost = O.render(scenes[name].flat, p)
+        ok = np.array_equal(img, ref) and (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
+        n += 1
+        if not ok:
+            print("MISMATCH", name, dict(tile=(x0, y0, x1, y1), spp=spp, seed=seed, flags=flags, max_depth=md, rows=rows, mem_budget=budget_b), flush=True)
+            sys.exit(1)
+    print(f"fuzz parity: {n} random configurations, all bit-identical to the oracle ({time.time() - t0:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()

@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256) void k_imul(uint32_t iters, float* __restrict_
     for (uint32_t it = 0; it < iters; ++it) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            a0 *= 0x7feb352du; a1 *= 0x846ca68bu; a2 *= 0x7feb352du; a3 *= 0x846ca68bu;
-            a4 *= 0x7feb352du; a5 *= 0x846ca68bu; a6 *= 0x7feb352du; a7 *= 0x846ca68bu;
+            // the xor keeps the compiler from folding the chain into one multiply by a power of the constant
+            a0 = (a0 * 0x7feb352du) ^ it; a1 = (a1 * 0x846ca68bu) ^ it; a2 = (a2 * 0x7feb352du) ^ it; a3 = (a3 * 0x846ca68bu) ^ it;
+            a4 = (a4 * 0x7feb352du) ^ it; a5 = (a5 * 0x846ca68bu) ^ it; a6 = (a6 * 0x7feb352du) ^ it; a7 = (a7 * 0x846ca68bu) ^ it;
         }
     }
     const uint32_t s = ((a0 ^ a1) ^ (a2 ^ a3)) ^ ((a4 ^ a5) ^ (a6 ^ a7));
@@ -257,7 +258,7 @@ int main(int argc, char** argv)
             CK(hipEventRecord(e1));
             const double ms = timeIt(e0, e1);
             if (rep == 0) continue;
-            const double ops = (double)cus * 8 * 4 * iters * (which == 0 ? 64.0 : 32.0);  // wave-level operations
+            const double ops = (double)cus * 8 * 4 * iters * (which == 0 ? 64.0 : 32.0);  // wave-level operations (imul: each paired with one v_xor)
             std::printf("%-52s %8.3f ms  %6.3f wave-ops/clk/SIMD (nominal clock) = one per %.1f clocks\n", name, ms, ops / (ms * 1e-3 * clk) / (cus * 4.0),
                         (ms * 1e-3 * clk) * (cus * 4.0) / ops);
         }
