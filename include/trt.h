@@ -146,6 +146,13 @@ typedef struct trt_scene {
 #define TRT_FLAG_FIXED_PIXELS 16u /* opt out of the pixel-grid quirks (Q1, Q2): pixel (i, j) samples its own cell
                                   * [j/W, (j+1)/W) x [(H-1-i)/H, (H-i)/H) of the image plane uniformly.  Off = parity mode. */
 
+#define TRT_FLAG_RAY_OFFSET 32u /* opt out of Q6 (rays start ON the surface they leave; only t < 0.0005, bvh.cpp:189, keeps them from
+                                  * hitting it again, and at the 1000-unit distances of the Cornell box the hit point's rounding error
+                                  * beats that for grazing directions): shadow and continuation rays start at P + s * eps * Ng, Ng the
+                                  * hit triangle's geometric normal, s the side the ray leaves to, eps = 1e-4 * max(1, |P.x|, |P.y|, |P.z|).
+                                  * Off = parity mode. */
+#define TRT_OFFSET_EPS 0.0001f
+
 typedef struct trt_params {
     int32_t width, height;   /* full image size (scene.img_width/height, scene.cpp:13-14) */
     int32_t spp;             /* SAMPLE (main.cpp:13,55) */

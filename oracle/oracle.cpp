@@ -318,6 +318,7 @@ inline int nextRay(const trt_material& m, V3 pn, V3 I, Stream& rng, V3& out)
 struct Vertex {
     V3 P, pn, wi, Kd;
     const trt_material* m;
+    V3 off;  // TRT_FLAG_RAY_OFFSET: eps * geometric normal of the hit triangle (zero otherwise)
 };
 
 // EXPERIMENT (tools/rank_ref_png.py --variants): estimator variants tried against the reference's `back` snapshots, which predate
@@ -360,12 +361,26 @@ struct PathTracer {
         } else {
             vx.Kd = ld(vx.m->Kd);
         }
+        vx.off = mk(0, 0, 0);
+        if (ray_offset) {
+            const Tri& T = sv.tris[h.tri];
+            const V3 ng = normalize(cross(T.e1, T.e2));
+            const float eps = TRT_OFFSET_EPS * fmaxf(1.0f, fmaxf(fabsf(vx.P.x), fmaxf(fabsf(vx.P.y), fabsf(vx.P.z))));
+            vx.off = ng * eps;
+        }
         return vx;
     }
 
     // One light of the NEE loop (pathTracing.cpp:34-74).  Returns true and the
     // unweighted contribution when the sample is visible and front-facing.
     bool fixed_nee = false;  // TRT_FLAG_FIXED_NEE: opt out of Q3 / Q4 / Q5 (include/trt.h)
+    bool ray_offset = false;  // TRT_FLAG_RAY_OFFSET: opt out of Q6
+    // origin of a ray leaving vx in direction w: the hit point (Q6), or eps off the surface on w's side
+    V3 rayOrigin(const Vertex& vx, V3 w) const
+    {
+        if (!ray_offset) return vx.P;
+        return dot(vx.off, w) >= 0.0f ? vx.P + vx.off : vx.P - vx.off;
+    }
 
     bool lightSample(const Vertex& vx, uint32_t li, Stream& rng, V3& contrib)
     {
@@ -394,9 +409,9 @@ struct PathTracer {
         if (!(cos_s > 0.0f)) return false;  // the reference traces and then discards (pathTracing.cpp:60)
         cnt.rays[1]++;
         if (fixed_nee) {  // visible iff nothing lies in [0.0005, 0.999 |x' - x|)
-            if (shadow.occluded(vx.P, wo, 0.999f * length(diff))) return false;
+            if (shadow.occluded(rayOrigin(vx, wo), wo, 0.999f * length(diff))) return false;
         } else {
-            const Hit h = shadow.closest(vx.P, wo);
+            const Hit h = shadow.closest(rayOrigin(vx, wo), wo);
             // Q5: visible iff the CLOSEST hit carries the light's material (pathTracing.cpp:54-58)
             if (h.tri < 0 || s->tri_mat[h.tri] != L.mat) return false;
         }
@@ -447,7 +462,7 @@ struct PathTracer {
                         if (type != TRT_RAY_INVALID) {
                             const V3 w = (type == TRT_RAY_TRANSMISSION) ? ld(vx.m->Tr) : vx.Kd;  // Q8
                             beta = g_experiment_no_rr_div ? beta * w : (beta * w) / TRT_P_RR;
-                            o = vx.P;  // Q6: no offset
+                            o = rayOrigin(vx, nd);  // Q6: no offset unless TRT_FLAG_RAY_OFFSET
                             d = nd;
                             prev_type = type;
                             cnt.rays[2]++;
@@ -488,9 +503,10 @@ struct PathTracer {
             const int type = nextRay(*vx.m, vx.pn, d, rng, nd);
             if (type != TRT_RAY_INVALID) {  // the reference also traces INVALID rays and drops the result
                 cnt.rays[2]++;
-                const Hit ret = closest.closest(vx.P, nd);
+                const V3 no = rayOrigin(vx, nd);
+                const Hit ret = closest.closest(no, nd);
                 if (ret.tri >= 0) {
-                    const V3 intensity = shadeRecursive(ret, vx.P, nd, rng, depth + 1) / TRT_P_RR;
+                    const V3 intensity = shadeRecursive(ret, no, nd, rng, depth + 1) / TRT_P_RR;
                     const bool ret_emissive = sv.emissive(ret.tri);
                     if (type == TRT_RAY_TRANSMISSION) L_indir = L_indir + ld(vx.m->Tr) * intensity;
                     else if (!ret_emissive) L_indir = L_indir + vx.Kd * intensity;
@@ -566,6 +582,7 @@ int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, o
         Counters cnt;
         PathTracer pt(sv, cnt);
         pt.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) != 0;
+        pt.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) != 0;
 #pragma omp for schedule(dynamic, 1)
         for (long r = 0; r < (long)rows.size(); ++r) {
             const int i = rows[(size_t)r];
@@ -836,6 +853,7 @@ int oracle_debug_path(const trt_scene* scene, const trt_params* p, int x, int y,
     Counters cnt;
     PathTracer pt(sv, cnt);
     pt.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) != 0;
+    pt.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) != 0;
     const uint32_t pixel = (uint32_t)y * (uint32_t)p->width + (uint32_t)x;
     Stream rng{trt_rng_make_key(p->seed, pixel, (uint32_t)sample), 0};
     const float u1 = rng.next(), u2 = rng.next();

@@ -157,6 +157,16 @@ struct Literal {
     std::vector<Tri> tris;
     std::vector<double> light_area;               // Material::area per light (scene.cpp:202)
     std::vector<std::vector<double>> light_cum;   // Triangle::area of the light's copies (scene.cpp:203)
+    bool ray_offset = false;  // TRT_FLAG_RAY_OFFSET (not the reference's: lets the tolerance be measured with Q6 out of the way)
+    // origin of a ray leaving the hit in direction w: the hit point, or eps off the surface on w's side (include/trt.h)
+    V3 rayOrigin(const HitRecord& rec, V3 w) const
+    {
+        if (!ray_offset) return rec.hitpoint;
+        const V3 P = rec.hitpoint;
+        const float eps = TRT_OFFSET_EPS * fmaxf(1.0f, fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z))));
+        const V3 off = tris[rec.tri].normal * eps;
+        return dot(off, w) >= 0.0f ? P + off : P - off;
+    }
 
     explicit Literal(const trt_scene* sc) : s(sc)
     {
@@ -346,7 +356,7 @@ struct Literal {
                 const V3 wo = normalize(light_p - rec.hitpoint);
                 if (dot(wo, rec.pn) > 0) {  // :60 (tested before the trace here; the trace has no side effect)
                     cnt.rays[1]++;
-                    const HitRecord rec_sample = traverseBVH(rec.hitpoint, wo);
+                    const HitRecord rec_sample = traverseBVH(rayOrigin(rec, wo), wo);
                     const bool visibility = rec_sample.tri >= 0 && s->tri_mat[rec_sample.tri] == L.mat;  // :55 (a miss carries mtl_name "")
                     if (visibility) {
                         const float pdf_light = (float)(double(1) / total_area);
@@ -367,7 +377,7 @@ struct Literal {
             const int type = nextRay(m, rec.pn, -wi, rng, nd);
             if (type != TRT_RAY_INVALID) {
                 cnt.rays[2]++;
-                const HitRecord ret = traverseBVH(rec.hitpoint, nd);
+                const HitRecord ret = traverseBVH(rayOrigin(rec, nd), nd);
                 if (ret.is_hit) {
                     const V3 intensity = shade(ret, -nd, rng, cnt, depth + 1) / TRT_P_RR;
                     if (type == TRT_RAY_TRANSMISSION) L_indir = L_indir + ld(m.Tr) * intensity;
@@ -396,7 +406,8 @@ int oracle_render_literal(const trt_scene* scene, const trt_params* p, float* ou
     if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 >= p->x1 || p->y0 >= p->y1) return TRT_EINVAL;
     if (scene->n_nodes < 1 || !scene->nodes) return TRT_EINVAL;
     if (p->max_depth != 0 || (p->flags & (TRT_FLAG_FIXED_NEE | TRT_FLAG_FIXED_PIXELS))) return TRT_EINVAL;  // the reference has neither
-    const Literal lit(scene);
+    Literal lit(scene);
+    lit.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) != 0;
     std::vector<int> rows;
     for (int y = p->y0; y < p->y1; ++y)
         if (rowSelected(p, y)) rows.push_back(y);

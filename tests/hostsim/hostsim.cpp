@@ -119,6 +119,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
     td.npix = npix; td.seed = p->seed; td.spp = (uint32_t)p->spp;
     td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
     td.fixed_pixels = (p->flags & TRT_FLAG_FIXED_PIXELS) ? 1u : 0u;
+    td.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) ? 1u : 0u;
     uint64_t r_cam = 0, r_sh = 0, r_ind = 0;
     const uint32_t S = (uint32_t)p->spp;  // one chunk: path id = s * npix + pixel
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : r_cam, r_sh, r_ind)
@@ -157,8 +158,8 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
                     const f3 w = cx.beta * contrib;
                     r_sh++;
                     // k_trace_shadow
-                    const Hit sh = hs.nk ? traceClosest<ArrayStack, false, 1>(hs.sc, cx.vx.P, wo, stk, ni, nt, t_max, fixed, !fixed)
-                                         : traceClosest<ArrayStack, false, 0>(hs.sc, cx.vx.P, wo, stk, ni, nt, t_max, fixed, !fixed);
+                    const Hit sh = hs.nk ? traceClosest<ArrayStack, false, 1>(hs.sc, rayOrigin(cx, wo), wo, stk, ni, nt, t_max, fixed, !fixed)
+                                         : traceClosest<ArrayStack, false, 0>(hs.sc, rayOrigin(cx, wo), wo, stk, ni, nt, t_max, fixed, !fixed);
                     if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)hs.sc.lights[li].mat)) L = L + w;
                 }
                 f4 nra, nrb, nbt;

@@ -643,3 +643,16 @@ def test_compressed_nodes_on_the_gpu(monkeypatch):
             assert rst.rays == ost.rays
         finally:
             r.close()
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("back", 128, 128, 16), ("veach-mis", 96, 54, 8), ("staircase", 64, 36, 8)])
+def test_ray_offset_flag_matches_oracle(name, w, h, spp, renderer_factory):
+    """TRT_FLAG_RAY_OFFSET (opt-out of Q6) through the wavefront kernels and k_tail, alone and with the other opt-outs."""
+    s = get_scene(name, w, h)
+    r = renderer_factory(s)
+    for flags in (T.TRT_FLAG_RAY_OFFSET, T.TRT_FLAG_RAY_OFFSET | T.TRT_FLAG_FIXED_NEE | T.TRT_FLAG_FIXED_PIXELS | T.TRT_FLAG_OVERLAP):
+        p = T.make_params(w, h, spp, 123, flags=flags)
+        img, st = r.render(p)
+        ref, ost = O.render(s.flat, p)
+        assert_same_image(img, ref, f"{name} ray offset flags={flags}")
+        assert (st.rays_camera, st.rays_shadow, st.rays_indirect, st.shaded_hits) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect, ost.shaded_hits)

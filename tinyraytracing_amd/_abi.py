@@ -17,6 +17,7 @@ TRT_FLAG_COUNT = 2
 TRT_FLAG_OVERLAP = 4
 TRT_FLAG_FIXED_NEE = 8
 TRT_FLAG_FIXED_PIXELS = 16
+TRT_FLAG_RAY_OFFSET = 32
 TRT_MAX_KERNELS = 8
 KERNEL_NAMES = ["gen_primary", "trace_closest", "shade", "trace_shadow", "resolve", "tail"]
 

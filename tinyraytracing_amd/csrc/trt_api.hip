@@ -630,6 +630,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     td.spp = (uint32_t)p->spp;
     td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
     td.fixed_pixels = (p->flags & TRT_FLAG_FIXED_PIXELS) ? 1u : 0u;
+    td.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) ? 1u : 0u;
 
     Timer tm;
     tm.h = h;

@@ -740,7 +740,8 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             parity = parity == 2 ? 0 : parity + 1;
             if (pend_emit) {
                 const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
-                A.sq[pend_li].sa[slot] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, pend_wo.x);  // Q6: origin = hit point, no offset
+                const f3 so = rayOrigin(c, pend_wo);  // Q6: the hit point itself unless TRT_FLAG_RAY_OFFSET
+                A.sq[pend_li].sa[slot] = mk4(so.x, so.y, so.z, pend_wo.x);
                 A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
                 A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
             }
@@ -753,7 +754,8 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         parity = parity == 2 ? 0 : parity + 1;
         if (pend_emit) {
             const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
-            A.sq[pend_li].sa[slot] = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, pend_wo.x);
+            const f3 so = rayOrigin(c, pend_wo);
+            A.sq[pend_li].sa[slot] = mk4(so.x, so.y, so.z, pend_wo.x);
             A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
             A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
         }
@@ -839,9 +841,9 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
                 Hit sh;
                 if (A.uniform) {
                     sh.t = fixed ? t_max : TRT_INF; sh.tri = -1; sh.flags = 0u; sh.u = 0.f; sh.v = 0.f;
-                    uniformWalk<COUNT>(sc, c.vx.P, wo, true, reinterpret_cast<f4*>(smem) + threadIdx.x, sh.t, sh.tri, sh.flags, ni[1], nt[1]);
+                    uniformWalk<COUNT>(sc, rayOrigin(c, wo), wo, true, reinterpret_cast<f4*>(smem) + threadIdx.x, sh.t, sh.tri, sh.flags, ni[1], nt[1]);
                 } else {
-                    sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT, NK>(sc, c.vx.P, wo, stk, ni[1], nt[1], t_max, fixed, !fixed);
+                    sh = traceClosest<LdsStack<TRT_LDS_STACK_MAX, true>, COUNT, NK>(sc, rayOrigin(c, wo), wo, stk, ni[1], nt[1], t_max, fixed, !fixed);
                 }
                 if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)sc.lights[li].mat)) { L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z; }
             }

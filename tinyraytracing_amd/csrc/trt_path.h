@@ -706,6 +706,7 @@ struct TileDesc {
     int32_t tile_w, x0, width, height;
     uint32_t fixed_nee;   // TRT_FLAG_FIXED_NEE
     uint32_t fixed_pixels;  // TRT_FLAG_FIXED_PIXELS
+    uint32_t ray_offset;    // TRT_FLAG_RAY_OFFSET
     uint32_t npix;        // rows * tile_w
     uint32_t seed, spp;
 };
@@ -747,7 +748,25 @@ struct ShadeCtx {
     Vertex vx;
     const MaterialDev* m;  // into the scene's table (LDS copy inside k_shade): fields are fetched where they are used, not held in registers
     Stream rng;
+    bool use_off;   // TRT_FLAG_RAY_OFFSET
+    f3 off;         // eps * Ng of the hit triangle (only with use_off)
 };
+
+// eps * geometric normal of triangle `tri` at hit point P (TRT_FLAG_RAY_OFFSET; the same expression in the oracle)
+TRT_HD inline f3 offsetVector(const TriIsect& T, f3 P)
+{
+    const f3 e1 = mk3(T.a.w, T.b.x, T.b.y), e2 = mk3(T.b.z, T.b.w, T.c.x);
+    const f3 ng = normalize(cross(e1, e2));
+    const float eps = TRT_OFFSET_EPS * fmaxf(1.0f, fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z))));
+    return ng * eps;
+}
+// where a ray that leaves the vertex in direction w starts: the hit point (Q6), or, with TRT_FLAG_RAY_OFFSET, eps off the surface
+// on w's side
+TRT_HD inline f3 rayOrigin(const ShadeCtx& c, f3 w)
+{
+    if (!c.use_off) return c.vx.P;
+    return dot(c.off, w) >= 0.0f ? c.vx.P + c.off : c.vx.P - c.off;
+}
 
 // First part of shade() (pathTracing.cpp:9-30) for the ray (ra, rb, bt) and its hit record.
 TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s0, const f4& ra, const f4& rb, const f4& bt, const f4& hit4, ShadeCtx& c)
@@ -761,6 +780,8 @@ TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s
     c.vx.mat = 0;
     c.m = sc.materials;  // any valid record: only dereferenced under had_hit
     c.rng.key.k0 = c.rng.key.k1 = 0; c.rng.ctr = 0;
+    c.use_off = td.ray_offset != 0u;
+    c.off = mk3(0, 0, 0);
     Hit h;
     h.t = hit4.x; h.tri = (int32_t)f2u(hit4.y); h.u = hit4.z; h.v = hit4.w; h.flags = 0;
     if (h.tri < 0) return;
@@ -786,6 +807,7 @@ TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s
     }
     c.shade_ok = true;
     c.vx = makeVertex(sc, h, o, c.d, ts, *c.m);
+    if (c.use_off) c.off = offsetVector(sc.tri_isect[h.tri], c.vx.P);
     c.rng.key = pathKey(td, s0, c.pid);
     c.rng.ctr = metaCtr(meta);
 }
@@ -802,7 +824,8 @@ TRT_HD inline bool shadeNext(ShadeCtx& c, int max_depth, f4& ra, f4& rb, f4& bt)
     if (type == TRT_RAY_INVALID) return false;
     const f3 w = (type == TRT_RAY_TRANSMISSION) ? ld3(c.m->Tr) : c.vx.Kd;  // Q8: SPECULAR is weighted by Kd too
     const f3 nb = (c.beta * w) / TRT_P_RR;
-    ra = mk4(c.vx.P.x, c.vx.P.y, c.vx.P.z, nd.x);  // Q6: origin = hit point, no offset
+    const f3 org = rayOrigin(c, nd);  // Q6: the hit point itself unless TRT_FLAG_RAY_OFFSET
+    ra = mk4(org.x, org.y, org.z, nd.x);
     rb = mk4(nd.y, nd.z, u2f(c.pid), u2f(packMeta(c.rng.ctr, (uint32_t)type, c.depth + 1)));
     bt = mk4(nb.x, nb.y, nb.z, 0.0f);
     return true;

@@ -18,7 +18,7 @@ static void usage()
 {
     std::fprintf(stderr,
                  "usage: tinyrt <basedir> <mtl> <xml> <obj> <spp> [--width W --height H] [--seed S] [--device D | --gpus N | --devices a,b,..]\n"
-                 "              [--leaf N] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels]\n"
+                 "              [--leaf N] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels] [--ray-offset]\n"
                  "              [--every N] [--checkpoint file.acc] [--stop-after M]\n"
                  "                                                    progressive: N samples per step, image rewritten after\n"
                  "                                                    every step, accumulator kept in file.acc (resumes from it)\n");
@@ -63,6 +63,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--out")) out_path = need("--out");
         else if (!std::strcmp(argv[i], "--fixed-nee")) opts.fixed_nee = true;
         else if (!std::strcmp(argv[i], "--fixed-pixels")) opts.fixed_pixels = true;
+        else if (!std::strcmp(argv[i], "--ray-offset")) opts.ray_offset = true;
         else if (!std::strcmp(argv[i], "--fixed")) opts.fixed_nee = opts.fixed_pixels = true;
         else if (!std::strcmp(argv[i], "--every")) opts.every = std::atoi(need("--every"));
         else if (!std::strcmp(argv[i], "--checkpoint")) opts.checkpoint = need("--checkpoint");

@@ -52,14 +52,15 @@ def compare(g, c):
 def main():
     name, w, h, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     threads = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0  # e.g. 32 = TRT_FLAG_RAY_OFFSET: the same measurement with Q6 out of the way
     sc = T.Scene.named(name, w, h)
-    p = T.make_params(w, h, spp, SEEDS[name])
+    p = T.make_params(w, h, spp, SEEDS[name], flags=flags)
     t0 = time.time()
     fast, sf = O.render(sc.flat, p, threads=threads)
     t1 = time.time()
     lit, sl = O.render_literal(sc.flat, p, threads=threads)
     t2 = time.time()
-    out = {"workload": f"{name} {w}x{h} {spp} spp, seed {SEEDS[name]:#x}", "fast_s": round(t1 - t0, 1), "literal_s": round(t2 - t1, 1),
+    out = {"workload": f"{name} {w}x{h} {spp} spp, seed {SEEDS[name]:#x}, flags {flags}", "fast_s": round(t1 - t0, 1), "literal_s": round(t2 - t1, 1),
            "rays_fast": {"camera": sf.rays_camera, "shadow": sf.rays_shadow, "indirect": sf.rays_indirect},
            "rays_literal": {"camera": sl.rays_camera, "shadow": sl.rays_shadow, "indirect": sl.rays_indirect}}
     out.update(compare(fast, lit))
