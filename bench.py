@@ -10,8 +10,9 @@ Prints ONE JSON line on rank 0 (DESIGN.md §5 explains every field):
   value / ms_per_step     wall clock of the K timed steps (barrier + synchronize on both sides, max over ranks)
   roofline                dominant kernel of the headline: algorithmic bytes (SURVEY.md §8d canonical sizes x counts
                           from an untimed counting render) / that kernel's hipEvent time in the timed steps
-  extra_workloads         (N = 1) the other rows of BASELINE.md §3 — veach-mis, staircase at 1080p/256 spp and the
-                          1 M-triangle soup of config 3 — timed the same way with fewer steps, each with its own roofline
+  extra_workloads         (N = 1) the other rows of BASELINE.md §3 — veach-mis, staircase at 1080p/256 spp, the 1 M-triangle
+                          soup of config 3 and config 5's 10 M-triangle scene at 3840x2160 / 64 spp per pass — timed the same
+                          way with fewer steps, each with its own roofline
   cpu_baseline            the oracle ("port") on one socket's physical cores, pinned, in a child process
 """
 import argparse
@@ -34,8 +35,10 @@ WORKLOADS = {
     "blob": "synthetic displaced geodesic sphere (Stanford-style mesh)",
 }
 SEEDS = {"back": 0x5EED0001, "veach-mis": 0x5EED0002, "staircase": 0x5EED0004, "soup": 0x5EED0003, "blob": 0x5EED0005}
-# (scene, spp, steps): BASELINE.md §3's other rows, timed after the headline when N = 1
-EXTRA = [("veach-mis", 256, 2), ("staircase", 256, 1), ("soup", 64, 2)]
+# (scene, spp, steps, width, height, triangles): BASELINE.md §3's other rows, timed after the headline when N = 1 — the other two cg22
+# scenes at the headline's size, config 3, and config 5's scene at the resolution and per-pass queue length of config 5
+EXTRA = [("veach-mis", 256, 2, None, None, None), ("staircase", 256, 1, None, None, None), ("soup", 64, 2, None, None, None),
+         ("blob", 64, 1, 3840, 2160, 10_000_000)]
 
 
 def parse():
@@ -266,8 +269,8 @@ def main():
         headline = (a.scene, a.width, a.height, a.spp) == ("back", 1920, 1080, 256)
         if world == 1 and headline and not a.no_extra and not a.fixed_nee and not a.overlap:
             extra = []
-            for name, spp, steps in EXTRA:
-                r, sc = B.measure(name, a.width, a.height, spp, steps, 1, SEEDS[name])
+            for name, spp, steps, ew, eh, etris in EXTRA:
+                r, sc = B.measure(name, ew or a.width, eh or a.height, spp, steps, 1, SEEDS[name], tris=etris)
                 extra.append({k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "rays_per_step", "roofline", "kernels_rank0", "simd_utilisation_traversal")})
                 sc.close()
             result["extra_workloads"] = extra
