@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak: random tiles / row interleaves / spp / seeds / flags / depth caps / memory budgets of the three cg22
-scenes (and a 50 k-triangle soup) rendered by the HIP path through the C-ABI and by the oracle; every image and every ray count
+scenes (and a 50 k-triangle soup) rendered by the HIP path through the C-ABI — default handles and handles on the optional code paths
+(quantised nodes, speculative scheduler, per-lane traversal of the tiny scene) — and by the oracle; every image and every ray count
 must be identical.  usage: tools/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
@@ -19,13 +20,23 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sizes = {"back": (257, 131), "veach-mis": (320, 180), "staircase": (192, 108), "soup": (160, 90)}
-    scenes, renderers = {}, {}
+    scenes, renderers, alt = {}, {}, {}
     for name, (w, h) in sizes.items():
         scenes[name] = T.Scene.named(name, w, h, **({"n": 50000} if name == "soup" else {}))
         renderers[name] = T.Renderer(scenes[name], 0)
+        # a second handle per scene on the optional code paths: quantised nodes + speculative scheduler (per-lane scenes),
+        # per-lane traversal instead of the uniform walk (tiny scene)
+        os.environ["TRT_NODE_KIND"] = "1"
+        os.environ["TRT_TRACE_IMPL"] = "4" if name != "back" else "3"
+        alt[name] = T.Renderer(scenes[name], 0)
+        del os.environ["TRT_NODE_KIND"], os.environ["TRT_TRACE_IMPL"]
     t0 = time.time()
+    t_print = t0
     n = 0
     while time.time() - t0 < budget:
+        if time.time() - t_print > 60:
+            print(f"... {n} configurations so far, all identical ({time.time() - t0:.0f} s)", flush=True)
+            t_print = time.time()
         name = list(sizes)[int(rng.integers(0, len(sizes)))]
         w, h = sizes[name]
         x0 = int(rng.integers(0, w - 1)); x1 = int(rng.integers(x0 + 1, min(w, x0 + 40) + 1))
@@ -37,6 +48,7 @@ def main():
         if rng.random() < 0.2: flags |= T.TRT_FLAG_FIXED_PIXELS
         if rng.random() < 0.4: flags |= T.TRT_FLAG_OVERLAP
         if rng.random() < 0.3: flags |= T.TRT_FLAG_COUNT
+        if rng.random() < 0.3: flags |= T.TRT_FLAG_RAY_OFFSET
         md = int(rng.choice([0, 0, 0, 1, 2, 5]))
         rows = None
         if rng.random() < 0.4:
@@ -47,7 +59,7 @@ def main():
         if not T.rows_selected(p):
             continue
         try:
-            img, st = renderers[name].render(p)
+            img, st = (alt if rng.random() < 0.4 else renderers)[name].render(p)
         except T.TrtError as e:
             if "mem_budget too small" in str(e):
                 continue
