@@ -253,7 +253,8 @@ void trt_destroy(trt_handle* h);
 typedef struct trt_group trt_group;
 int trt_group_create(const trt_scene* scene, int n_devices, const int* devices, trt_group** out);
 /* p: as for trt_render (tile, spp, seed, flags); p->row_block (>= 1; 0 = 8) is the stripe height, row_mod / row_rem are
- * set by the library.  out_rgb_host: (y1-y0) * (x1-x0) * 3 floats.  stats (optional): rays / launches / kernel_ms summed
+ * set by the library; the tile's first row p->y0 must be a multiple of row_block * group size (TRT_EINVAL otherwise: stripes are
+ * counted from image row 0).  out_rgb_host: (y1-y0) * (x1-x0) * 3 floats.  stats (optional): rays / launches / kernel_ms summed
  * over the devices, render_ms = the slowest device's, plus gather_ms = gather + un-interleave on devices[0]. */
 int trt_group_render(trt_group* g, const trt_params* p, float* out_rgb_host, trt_stats* stats, double* gather_ms);
 int trt_group_size(const trt_group* g);
