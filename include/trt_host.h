@@ -32,6 +32,11 @@ typedef struct trth_scene trth_scene;
 trth_scene* trth_scene_load(const char* xml_path, const char* obj_path, const char* mtl_path,
                             const char* basedir, int width, int height);
 
+/* The same with loader options: triangulate_polygons != 0 turns an `f` line of n > 3 vertices into the fan (v0,v1,v2), (v0,v2,v3), ...
+ * instead of keeping its first three vertices only (what the reference does, scene.cpp:162, and what trth_scene_load does). */
+trth_scene* trth_scene_load_opts(const char* xml_path, const char* obj_path, const char* mtl_path,
+                                 const char* basedir, int width, int height, int triangulate_polygons);
+
 /* Removes triangles [first, first+count) in file order (before the BVH build). */
 int trth_scene_drop_tris(trth_scene* s, uint32_t first, uint32_t count);
 /* Synthetic geometry added to a loaded base scene (scenes/back): see host/synth.cpp. */

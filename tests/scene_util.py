@@ -25,9 +25,10 @@ def write_scene(tmpdir, name, obj_text, mtl_text, lights=(), w=32, h=32, fovy=40
     return d
 
 
-def load(tmpdir, name, leaf_num=2, builder="auto", width=0, height=0):
+def load(tmpdir, name, leaf_num=2, builder="auto", width=0, height=0, triangulate_polygons=False):
     d = str(tmpdir)
-    s = T.Scene.load(os.path.join(d, name + ".xml"), os.path.join(d, name + ".obj"), os.path.join(d, name + ".mtl"), d, width, height)
+    s = T.Scene.load(os.path.join(d, name + ".xml"), os.path.join(d, name + ".obj"), os.path.join(d, name + ".mtl"), d, width, height,
+                     triangulate_polygons=triangulate_polygons)
     s.build_bvh(leaf_num, builder)
     return s
 

@@ -207,3 +207,19 @@ def test_synthetic_scenes_build():
     # deterministic
     s2 = T.Scene.named("soup", 64, 36, n=5000)
     assert np.array_equal(np.sort(s.arrays()["tri_v"].reshape(-1)), np.sort(s2.arrays()["tri_v"].reshape(-1)))
+
+
+def test_polygons_are_fanned_only_on_request(tmp_path):
+    """An `f` line with four or five vertices: the reference (scene.cpp:162) and the default loader keep the first three tokens;
+    triangulate_polygons turns it into the fan (v0,v1,v2), (v0,v2,v3), ... — also for the light's area / CDF."""
+    obj = ("v 0 0 0\nv 2 0 0\nv 2 2 0\nv 0 2 0\nv -1 1 0\nvt 0 0\nvn 0 0 1\n"
+           "usemtl lamp\nf 1/1/1 2/1/1 3/1/1 4/1/1\n"
+           "usemtl white\nf 1/1/1 2/1/1 3/1/1 4/1/1 5/1/1\n")
+    SU.write_scene(tmp_path, "poly", obj, SU.MTL_BASIC, lights=[("lamp", (1, 1, 1))], w=16, h=16)
+    s3 = SU.load(tmp_path, "poly")
+    assert s3.info["n_triangles"] == 2 and abs(s3.light_area(0) - 2.0) < 1e-5
+    sp = SU.load(tmp_path, "poly", triangulate_polygons=True)
+    assert sp.info["n_triangles"] == 2 + 3 and abs(sp.light_area(0) - 4.0) < 1e-5
+    tv = sp.arrays()["tri_v"]
+    areas = 0.5 * np.linalg.norm(np.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0]), axis=1)
+    assert abs(areas.sum() - (4.0 + 5.0)) < 1e-4   # the quad twice over + the pentagon's extra triangle (area 1)

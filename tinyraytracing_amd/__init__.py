@@ -52,12 +52,13 @@ class Scene:
         self._built = False
 
     @classmethod
-    def load(cls, xml_path, obj_path, mtl_path, basedir, width=0, height=0):
+    def load(cls, xml_path, obj_path, mtl_path, basedir, width=0, height=0, triangulate_polygons=False):
         """scene.readxml(xml); scene.readobj(obj); scene.readmtl(mtl, basedir) (main.cpp:66-69).
-        width/height override the XML resolution."""
+        width/height override the XML resolution; triangulate_polygons fans faces of more than three vertices instead of
+        keeping their first three only (the reference's behaviour, scene.cpp:162, and the default)."""
         lib = _abi.load_host()
-        h = lib.trth_scene_load(os.fsencode(xml_path), os.fsencode(obj_path), os.fsencode(mtl_path),
-                                os.fsencode(basedir), int(width), int(height))
+        h = lib.trth_scene_load_opts(os.fsencode(xml_path), os.fsencode(obj_path), os.fsencode(mtl_path),
+                                     os.fsencode(basedir), int(width), int(height), 1 if triangulate_polygons else 0)
         if not h:
             raise TrtError(lib.trth_last_error().decode())
         return cls(h)

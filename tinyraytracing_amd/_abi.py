@@ -84,7 +84,7 @@ class Stats(C.Structure):
 # the symbols include/trt.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = ["trt_rows_selected", "trt_create", "trt_render", "trt_render_device", "trt_render_samples", "trt_trace_closest",
                "trt_destroy", "trt_last_error", "trt_abi_version", "trt_group_create", "trt_group_render", "trt_group_size", "trt_group_destroy"]
-HOST_SYMBOLS = ["trth_scene_load", "trth_scene_drop_tris", "trth_scene_add_soup", "trth_scene_add_blob",
+HOST_SYMBOLS = ["trth_scene_load", "trth_scene_load_opts", "trth_scene_drop_tris", "trth_scene_add_soup", "trth_scene_add_blob",
                 "trth_scene_build", "trth_scene_flat", "trth_scene_info", "trth_scene_light_area",
                 "trth_scene_material_name", "trth_scene_free", "trth_tonemap", "trth_write_png",
                 "trth_write_png_bytes", "trth_decode_jpeg", "trth_abi_sizes", "trth_last_error"]
@@ -104,6 +104,8 @@ def load_host():
     lib.trth_last_error.restype = C.c_char_p
     lib.trth_scene_load.restype = C.c_void_p
     lib.trth_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    lib.trth_scene_load_opts.restype = C.c_void_p
+    lib.trth_scene_load_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
     lib.trth_scene_drop_tris.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.trth_scene_add_soup.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     lib.trth_scene_add_blob.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]

@@ -28,8 +28,14 @@ const char* trth_last_error(void) { return g_err.c_str(); }
 
 trth_scene* trth_scene_load(const char* xml_path, const char* obj_path, const char* mtl_path, const char* basedir, int width, int height)
 {
+    return trth_scene_load_opts(xml_path, obj_path, mtl_path, basedir, width, height, 0);
+}
+
+trth_scene* trth_scene_load_opts(const char* xml_path, const char* obj_path, const char* mtl_path, const char* basedir, int width, int height, int triangulate_polygons)
+{
     if (!xml_path || !obj_path || !mtl_path || !basedir) { fail("trth_scene_load: null path"); return nullptr; }
     std::unique_ptr<trth_scene> s(new trth_scene);
+    s->scene.triangulate_polygons = triangulate_polygons != 0;
     try {
         s->scene.readxml(xml_path);
         if (width > 0 && height > 0) s->scene.setResolution(width, height);

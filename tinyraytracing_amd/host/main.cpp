@@ -18,7 +18,7 @@ static void usage()
 {
     std::fprintf(stderr,
                  "usage: tinyrt <basedir> <mtl> <xml> <obj> <spp> [--width W --height H] [--seed S] [--device D | --gpus N | --devices a,b,..]\n"
-                 "              [--leaf N] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels] [--ray-offset]\n"
+                 "              [--leaf N] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels] [--ray-offset] [--polygons]\n"
                  "              [--every N] [--checkpoint file.acc] [--stop-after M]\n"
                  "                                                    progressive: N samples per step, image rewritten after\n"
                  "                                                    every step, accumulator kept in file.acc (resumes from it)\n");
@@ -32,6 +32,7 @@ int main(int argc, char** argv)
     opts.spp = std::atoi(argv[5]);
     opts.timing = true;
     int width = 0, height = 0;
+    bool polygons = false;  // fan-triangulate faces of more than three vertices (the reference keeps their first three only)
     std::string out_path;
     for (int i = 6; i < argc; ++i) {
         auto need = [&](const char* flag) -> const char* {
@@ -64,6 +65,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--fixed-nee")) opts.fixed_nee = true;
         else if (!std::strcmp(argv[i], "--fixed-pixels")) opts.fixed_pixels = true;
         else if (!std::strcmp(argv[i], "--ray-offset")) opts.ray_offset = true;
+        else if (!std::strcmp(argv[i], "--polygons")) polygons = true;
         else if (!std::strcmp(argv[i], "--fixed")) opts.fixed_nee = opts.fixed_pixels = true;
         else if (!std::strcmp(argv[i], "--every")) opts.every = std::atoi(need("--every"));
         else if (!std::strcmp(argv[i], "--checkpoint")) opts.checkpoint = need("--checkpoint");
@@ -73,6 +75,7 @@ int main(int argc, char** argv)
     try {
         const auto t0 = std::chrono::steady_clock::now();
         trt::Scene scene;
+        scene.triangulate_polygons = polygons;
         scene.readxml(xml);   // the order cannot be changed (main.cpp:66)
         if (width > 0 && height > 0) scene.setResolution(width, height);
         scene.readobj(obj);

@@ -366,16 +366,19 @@ void Scene::readobj(const std::string& obj_path)
             sin >> mtl_name;
             mtl_id = materialId(mtl_name);
         } else if (key == "f") {
-            // Only the first three vertex tokens are used (scene.cpp:162).
-            std::string tok[3];
-            sin >> tok[0] >> tok[1] >> tok[2];
-            if (tok[2].empty()) throw std::runtime_error("obj: face with fewer than three vertices");
+            // Only the first three vertex tokens are used (scene.cpp:162) — unless triangulate_polygons asks for the fan.
+            std::vector<std::string> toks;
+            for (std::string t; sin >> t;) toks.push_back(t);
+            if (toks.size() < 3) throw std::runtime_error("obj: face with fewer than three vertices");
             if (mtl_id < 0) mtl_id = materialId(mtl_name);
+            const size_t n_fan = (triangulate_polygons && toks.size() > 3) ? toks.size() - 2 : 1;
+            for (size_t f = 0; f < n_fan; ++f) {
+            const std::string* tok3[3] = {&toks[0], &toks[f + 1], &toks[f + 2]};
             Triangle tri;
             bool have_vn = true;
             for (int k = 0; k < 3; ++k) {
                 long idx[3];
-                parseFaceToken(tok[k], idx);
+                parseFaceToken(*tok3[k], idx);
                 tri.v[k] = pick(vertices, idx[0], "vertex");
                 // The slot-order quirk applies to the full a/b/c form the reference parses; the
                 // forms it cannot parse follow the OBJ standard: a//c = v//vn, a/b = v/vt.
@@ -399,6 +402,7 @@ void Scene::readobj(const std::string& obj_path)
                 m.triangles.push_back(tri);
             }
             triangles.push_back(std::move(tri));
+            }
         }
     }
     n_vertices = (int)vertices.size();

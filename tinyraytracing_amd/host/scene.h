@@ -35,6 +35,11 @@ public:
     std::unordered_map<std::string, int> material_ids;
     Camera camera;
 
+    // Faces with more than three vertices: the reference reads the first three tokens of an `f` line and silently drops the rest
+    // (scene.cpp:162) — that stays the default.  With triangulate_polygons a face of n vertices becomes the fan
+    // (v0,v1,v2), (v0,v2,v3), ... in file order (what an OBJ exporter means by a quad).  Set before readobj().
+    bool triangulate_polygons = false;
+
     // loader statistics (the counts the reference prints, scene.cpp:209-212)
     int n_vertices = 0, n_vn = 0, n_vt = 0;
 };
