@@ -48,6 +48,7 @@ def assemble(stripes, width, height, world, row_block=ROW_BLOCK):
 
 
 _row_index_cache = {}
+_gather_cache = {}
 
 
 def _row_indices(width, height, world, row_block, device):
@@ -67,7 +68,8 @@ def render_distributed(render_fn, width, height, spp, seed, dist=None, device=No
     """Renders this rank's stripes with `render_fn(params) -> (array-or-tensor [rows, width, 3], stats)`
     and gathers them on rank 0.  Returns (image tensor [height, width, 3] on rank 0 else None, stats of
     this rank).  The image stays where the gather ran: on the GPU with RCCL (`device` given, backend
-    nccl), on the CPU with gloo.
+    nccl), on the CPU with gloo.  With more than one rank the returned tensor is rank 0's landing buffer and is
+    overwritten by the next call: clone it to keep it.
 
     `dist` is torch.distributed (already initialised) or None for a single process."""
     import torch
@@ -90,11 +92,18 @@ def render_distributed(render_fn, width, height, spp, seed, dist=None, device=No
         buf[:nrows] = t.reshape(nrows, width, 3)
     if buf.is_cuda and dist.get_backend() != "nccl":
         buf = buf.cpu()  # gloo gathers host tensors (tests, rehearsals); RCCL gathers device to device over xGMI
-    gather_list = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    # rank 0's landing buffers are kept between calls (bench.py calls this once per step: at 8 ranks a step is ~12 ms)
+    gather_list = None
+    if rank == 0:
+        key = (pad_rows, width, world, str(buf.device))
+        if key not in _gather_cache:
+            _gather_cache.clear()
+            _gather_cache[key] = ([torch.empty_like(buf) for _ in range(world)], torch.empty((height, width, 3), dtype=torch.float32, device=buf.device))
+        gather_list = _gather_cache[key][0]
     dist.gather(buf, gather_list, dst=0)  # the single collective of the data path
     if rank != 0:
         return None, stats
-    img = torch.empty((height, width, 3), dtype=torch.float32, device=buf.device)
+    img = _gather_cache[key][1]
     for r, idx in enumerate(_row_indices(width, height, world, row_block, buf.device)):
         img.index_copy_(0, idx, gather_list[r][: idx.numel()])
     return img, stats
