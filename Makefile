@@ -12,7 +12,11 @@ OUT := $(PKG)/lib
 # FMA only where the source says fmaf.  x86-64-v3 = AVX2 + hardware FMA.
 CPU_FP := -ffp-contract=off -march=x86-64-v3
 CXXFLAGS := -O2 -g0 -std=c++17 -fPIC -Wall -Wextra $(CPU_FP) -Iinclude -I$(PKG)/host
+# The LLVM atomic optimizer turns the one-lane queue reservation of k_shade (blockStage) into "atomic; s_waitcnt vmcnt(0);
+# readfirstlane", i.e. waits for the round trip (and every store before it) on the spot; the kernel consumes the value one
+# stage later.  No kernel here relies on that pass: every atomic is issued by one lane per wave already.
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
+            -mllvm -amdgpu-atomic-optimizer-strategy=None \
             -Wall -Wextra -Wno-unused-parameter -Iinclude -I$(PKG)/csrc
 
 HOST_SRC := $(PKG)/host/scene.cpp $(PKG)/host/bvh.cpp $(PKG)/host/synth.cpp $(PKG)/host/image_out.cpp $(PKG)/host/jpeg.cpp $(PKG)/host/capi.cpp

@@ -77,7 +77,8 @@ struct trt_handle {
     std::vector<uint32_t> light_mats;
     uint32_t depth = 0;       // stack entries a traversal can need (wide tree), + 1
     uint32_t bvh2_depth = 0;  // depth of the caller's BVH2
-    uint32_t lds_tab[4] = {0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles that k_shade stages in LDS
+    uint32_t shade_tabs = 0;  // which k_shade<TABS> this scene runs
+    uint32_t lds_tab[5] = {0, 0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles / (tiny scenes) shading triangles that k_shade stages in LDS
     int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
     int node_kind = 0;        // what the per-lane traversal walks: 0 exact 128-B wide nodes, 1 compressed 64-B nodes (trt_path.h CNode)
     // Grid of the traversal kernels for a queue of n rays.  A persistent wave refills finished lanes from its own slice
@@ -471,14 +472,23 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     h->sc.cam = s->camera;
     for (uint32_t i = 0; i < s->n_lights; ++i) h->light_mats.push_back((uint32_t)s->lights[i].mat);
     {   // which small tables k_shade copies into LDS: in this order while they fit (uploads are padded to 16 B)
-        const uint32_t want[4] = {(uint32_t)(s->n_materials * sizeof(MaterialDev)), (uint32_t)(s->n_lights * sizeof(LightDev)),
-                                  h->sc.light_cum ? (uint32_t)(s->n_light_tris * sizeof(float)) : 0u, (uint32_t)(s->n_light_tris * sizeof(LightTriDev))};
+        // the per-triangle shading records only for scenes of a few dozen triangles (every block pays for the copy)
+        const uint32_t want[5] = {(uint32_t)(s->n_materials * sizeof(MaterialDev)), (uint32_t)(s->n_lights * sizeof(LightDev)),
+                                  h->sc.light_cum ? (uint32_t)(s->n_light_tris * sizeof(float)) : 0u, (uint32_t)(s->n_light_tris * sizeof(LightTriDev)),
+                                  s->n_tris <= 64 ? (uint32_t)(s->n_tris * sizeof(TriShade)) : 0u};
         uint32_t used = 0;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 5; ++k) {
             const uint32_t padded = (want[k] + 15u) & ~15u;
             if (want[k] && used + padded <= TRT_SHADE_LDS_TABLE_BYTES) { h->lds_tab[k] = want[k]; used += padded; }
         }
-        if (std::getenv("TRT_SHADE_NO_LDS")) h->lds_tab[0] = h->lds_tab[1] = h->lds_tab[2] = h->lds_tab[3] = 0;
+        if (std::getenv("TRT_SHADE_NO_LDS")) h->lds_tab[0] = h->lds_tab[1] = h->lds_tab[2] = h->lds_tab[3] = h->lds_tab[4] = 0;
+        if (std::getenv("TRT_SHADE_NO_LDS_TRIS")) h->lds_tab[4] = 0;
+        // k_shade is instantiated for these sets of staged tables; take the largest one that fits
+        uint32_t have = 0;
+        for (int k = 0; k < 5; ++k) have |= h->lds_tab[k] ? (1u << k) : 0u;
+        h->shade_tabs = 0;
+        for (uint32_t m : {31u, 15u, 7u, 3u})
+            if ((have & m) == m) { h->shade_tabs = m; break; }
     }
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
@@ -711,9 +721,19 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         A.lds_light_bytes = h->lds_tab[1];
         A.lds_cum_bytes = h->lds_tab[2];
         A.lds_ltri_bytes = h->lds_tab[3];
+        A.lds_tshade_bytes = h->lds_tab[4];
         A.stats = d_stats;
         tm.begin(TRT_K_SHADE, S.stream);
-        hipLaunchKernelGGL(k_shade, dim3(std::min<uint32_t>((S.n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u)), dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A);
+        {
+            const dim3 grid(std::min<uint32_t>((S.n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u));
+            switch (h->shade_tabs) {
+                case 31u: hipLaunchKernelGGL(k_shade<31u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
+                case 15u: hipLaunchKernelGGL(k_shade<15u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
+                case 7u: hipLaunchKernelGGL(k_shade<7u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
+                case 3u: hipLaunchKernelGGL(k_shade<3u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
+                default: hipLaunchKernelGGL(k_shade<0u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
+            }
+        }
         tm.end(S.stream);
         st.launches[TRT_K_SHADE]++;
         // (b, c) and (b + 1, c) of the counters in use -> host_counts[2 * c], [2 * c + 1], then the sequence word

@@ -658,35 +658,40 @@ struct ShadeArgs {
     uint32_t s0;
     int32_t max_depth;
     uint32_t primary;         // bounce 0: entry i is the camera ray of path i (not in HBM); Lacc is initialised here
-    // Small scene tables staged in LDS by every block (byte counts; 0 = leave that table in global memory):
+    // Byte counts of the small scene tables that k_shade<TABS> stages in LDS (read only for the tables of TABS):
     // material / light / CDF / light-triangle look-ups then cost an LDS access instead of a dependent
-    // global round trip each — k_shade is bound by exactly that chain of round trips.
-    uint32_t lds_mat_bytes, lds_light_bytes, lds_cum_bytes, lds_ltri_bytes;
+    // global round trip each.
+    uint32_t lds_mat_bytes, lds_light_bytes, lds_cum_bytes, lds_ltri_bytes, lds_tshade_bytes;
     DeviceStats* stats;
 };
 
 constexpr uint32_t TRT_SHADE_LDS_TABLE_BYTES = 24 * 1024;
 
+// TABS: bit k set = table k (materials, lights, light CDF, light triangles, shading triangles) is staged in LDS by this
+// instantiation.  A compile-time choice so that every table access is a plain LDS (ds_read) or global load: behind a
+// run-time choice the pointers are generic, the accesses FLAT, and each of them waits for vmcnt(0) — i.e. for the ray
+// stores issued before it — as well as for the LDS.
+template <uint32_t TABS>
 __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
 {
     __shared__ uint32_t s_cnt[3 * (TRT_SHADE_BLOCK / 64 + 1)];
     __shared__ uint32_t s_shaded, s_anyhit;
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[TRT_SHADE_LDS_TABLE_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[TABS ? TRT_SHADE_LDS_TABLE_BYTES / 4 : 4];
     if (threadIdx.x == 0) { s_shaded = 0; s_anyhit = 0; }
-    {   // stage the tables that fit (16-byte words, coalesced), then point this block's scene view at them
+    {   // stage the tables (16-byte words, coalesced), then point this block's scene view at them
         uint32_t off = 0;
         auto stage = [&](const void* src, uint32_t bytes) -> const void* {
-            if (bytes == 0) return src;
             const f4* g = reinterpret_cast<const f4*>(src);
             f4* l = reinterpret_cast<f4*>(s_tab + off / 4);
             for (uint32_t w = threadIdx.x; w < (bytes + 15u) / 16u; w += TRT_SHADE_BLOCK) l[w] = g[w];
             off += (bytes + 15u) & ~15u;
             return l;
         };
-        sc.materials = static_cast<const MaterialDev*>(stage(sc.materials, A.lds_mat_bytes));
-        sc.lights = static_cast<const LightDev*>(stage(sc.lights, A.lds_light_bytes));
-        sc.light_cum = static_cast<const float*>(stage(sc.light_cum, A.lds_cum_bytes));
-        sc.light_tris = static_cast<const LightTriDev*>(stage(sc.light_tris, A.lds_ltri_bytes));
+        if (TABS & 1u) sc.materials = static_cast<const MaterialDev*>(stage(sc.materials, A.lds_mat_bytes));
+        if (TABS & 2u) sc.lights = static_cast<const LightDev*>(stage(sc.lights, A.lds_light_bytes));
+        if (TABS & 4u) sc.light_cum = static_cast<const float*>(stage(sc.light_cum, A.lds_cum_bytes));
+        if (TABS & 8u) sc.light_tris = static_cast<const LightTriDev*>(stage(sc.light_tris, A.lds_ltri_bytes));
+        if (TABS & 16u) sc.tri_shade = static_cast<const TriShade*>(stage(sc.tri_shade, A.lds_tshade_bytes));
     }
     __syncthreads();
     int parity = 0;
@@ -747,11 +752,19 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             }
             pend_s = s; pend_emit = emit; pend_rank = rank; pend_li = li; pend_wo = wo; pend_w = c.beta * contrib; pend_tmax = t_max;
         }
-        f4 nra, nrb, nbt;
-        const bool emit_next = shadeNext(c, A.max_depth, nra, nrb, nbt);
+        // The extension ray in two halves around its reservation: the decision (RR, lobe draws) before the barrier, the
+        // direction (Sample / refract: the long part) behind the atomic, whose round trip it covers.  All ray stores of
+        // the last two stages come after the last barrier: a wave that has stores in flight when it needs an atomic's
+        // result waits for vmcnt(0), i.e. for the stores as well, and the block waits for that wave.
+        NextPlan plan;
+        const bool emit_next = shadeNextDecide(c, A.max_depth, plan);
         uint32_t rank_next;
         uint32_t* s_next = blockStage<TRT_SHADE_BLOCK>(emit_next, A.next_count, s_cnt, parity, rank_next, pend_s, pend_base);
         parity = parity == 2 ? 0 : parity + 1;
+        f4 nra = mk4(0, 0, 0, 0), nrb = nra, nbt = nra;
+        if (emit_next) shadeNextFinish(c, plan, nra, nrb, nbt);
+        if (threadIdx.x == 0) s_next[TRT_SHADE_BLOCK / 64] = pend_base;  // publish the last base
+        __syncthreads();
         if (pend_emit) {
             const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
             const f3 so = rayOrigin(c, pend_wo);
@@ -759,8 +772,6 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
             A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
         }
-        if (threadIdx.x == 0) s_next[TRT_SHADE_BLOCK / 64] = pend_base;  // publish the last base
-        __syncthreads();
         if (emit_next) {
             const uint32_t slot = s_next[TRT_SHADE_BLOCK / 64] + s_next[threadIdx.x >> 6] + rank_next;
             A.qout.ra[slot] = nra;
@@ -866,7 +877,9 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
             atomicAdd(&A.stats->inner_visits[1], c2); atomicAdd(&A.stats->tri_tests[1], c3);
         }
     }
-    if (any) atomicMax(&A.stats->max_depth_hit, deepest);
+    uint32_t dm = any ? deepest + 1u : 0u;  // wave maximum, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(dm, off); dm = o > dm ? o : dm; }
+    if ((threadIdx.x & 63) == 0 && dm) atomicMax(&A.stats->max_depth_hit, dm - 1u);
 }
 
 // ---------------------------------------------------------------- K6 ----

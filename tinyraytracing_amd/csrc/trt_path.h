@@ -543,25 +543,24 @@ TRT_HD inline f3 sampleDir(f3 a, int ray_type, float Ns, float u_phi, float u_th
 }
 
 // ---------------------------------------------------------- nextRay (a11) ----
-// pathTracing.cpp:147-209; I = incoming direction.
-TRT_HD inline int nextRay(const MaterialDev& m, f3 pn, f3 I, Stream& rng, f3& out)
+// pathTracing.cpp:147-209; I = incoming direction.  In two halves, so that a kernel can put a queue reservation between
+// them: nextRayDecide makes every random draw and every branch decision that tells WHETHER a ray leaves the vertex (cheap);
+// nextRayFinish builds its direction (refract / reflect / Sample: the expensive part) and its type.  nextRay = both.
+struct NextPlan {
+    int kind;  // 0: INVALID (no ray), 1: Fresnel transmission branch, 2: diffuse lobe, 3: specular lobe
+    float u_phi, u_theta;
+};
+TRT_HD inline NextPlan nextRayDecide(const MaterialDev& m, f3 pn, f3 I, Stream& rng)
 {
+    NextPlan pl;
+    pl.kind = 0; pl.u_phi = 0.0f; pl.u_theta = 0.0f;
     if (m.Ni > 1.0f) {
         const float cos_in = dot(I, pn);
-        f3 n;
-        float eta;  // n1 / n2
-        if (cos_in > 0.0f) { n = -pn; eta = m.Ni; }         // n1 = Ni, n2 = 1:  Ni / 1 == Ni
-        else { n = pn; eta = m.Ni_inv; }                    // n1 = 1, n2 = Ni
         const float rf0 = m.rf0;  // ((n1 - n2) / (n1 + n2))^2, makeMaterialDev
         const float x = 1.0f - fabsf(cos_in);
         const float x2 = x * x;
         const float fresnel = rf0 + (1.0f - rf0) * ((x2 * x2) * x);
-        if (fresnel < rng.next()) {
-            const f3 T = refract(I, n, eta);
-            if (T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) { out = T; return TRT_RAY_TRANSMISSION; }
-            out = reflect(I, n);
-            return TRT_RAY_SPECULAR;
-        }
+        if (fresnel < rng.next()) { pl.kind = 1; return pl; }
     }
     const float kd = m.sel_kd, kdks = m.sel_kdks;  // |Kd| / (|Kd| + |Ks|) and that + |Ks| / (|Kd| + |Ks|), makeMaterialDev
     // the lobe draw p lies in [0, 1): a purely diffuse material (kd == 1) takes the diffuse lobe whatever p is, so the
@@ -569,18 +568,41 @@ TRT_HD inline int nextRay(const MaterialDev& m, f3 pn, f3 I, Stream& rng, f3& ou
     float p = 0.0f;
     if (kd >= 1.0f) rng.ctr++;
     else p = rng.next();
-    if (p < kd) {
-        const float u_phi = rng.next(), u_theta = rng.next();
-        out = sampleDir(pn, TRT_RAY_DIFFUSE, m.Ns, u_phi, u_theta);
+    if (p < kd) pl.kind = 2;
+    else if (m.Ns > 1.0f && p < kdks) pl.kind = 3;
+    else return pl;
+    pl.u_phi = rng.next();
+    pl.u_theta = rng.next();
+    return pl;
+}
+TRT_HD inline int nextRayFinish(const MaterialDev& m, f3 pn, f3 I, const NextPlan& pl, f3& out)
+{
+    if (pl.kind == 1) {
+        const float cos_in = dot(I, pn);
+        f3 n;
+        float eta;  // n1 / n2
+        if (cos_in > 0.0f) { n = -pn; eta = m.Ni; }         // n1 = Ni, n2 = 1:  Ni / 1 == Ni
+        else { n = pn; eta = m.Ni_inv; }                    // n1 = 1, n2 = Ni
+        const f3 T = refract(I, n, eta);
+        if (T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) { out = T; return TRT_RAY_TRANSMISSION; }
+        out = reflect(I, n);
+        return TRT_RAY_SPECULAR;
+    }
+    if (pl.kind == 2) {
+        out = sampleDir(pn, TRT_RAY_DIFFUSE, m.Ns, pl.u_phi, pl.u_theta);
         return TRT_RAY_DIFFUSE;
     }
-    if (m.Ns > 1.0f && p < kdks) {
-        const float u_phi = rng.next(), u_theta = rng.next();
-        out = sampleDir(reflect(I, pn), TRT_RAY_SPECULAR, m.Ns, u_phi, u_theta);
+    if (pl.kind == 3) {
+        out = sampleDir(reflect(I, pn), TRT_RAY_SPECULAR, m.Ns, pl.u_phi, pl.u_theta);
         return TRT_RAY_SPECULAR;
     }
     out = mk3(0.f, 0.f, 0.f);
     return TRT_RAY_INVALID;
+}
+TRT_HD inline int nextRay(const MaterialDev& m, f3 pn, f3 I, Stream& rng, f3& out)
+{
+    const NextPlan pl = nextRayDecide(m, pn, I, rng);
+    return nextRayFinish(m, pn, I, pl, out);
 }
 
 // ------------------------------------------------------ path vertex (a5/a8) ----
@@ -812,22 +834,34 @@ TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s
     c.rng.ctr = metaCtr(meta);
 }
 
-// Last part of shade() (pathTracing.cpp:78-99): RR(0.8), nextRay, beta update.
-// Returns true when an extension ray leaves the vertex; INVALID rays are not traced.
-TRT_HD inline bool shadeNext(ShadeCtx& c, int max_depth, f4& ra, f4& rb, f4& bt)
+// Last part of shade() (pathTracing.cpp:78-99): RR(0.8), nextRay, beta update — in the two halves of nextRay.
+// shadeNextDecide returns true when an extension ray leaves the vertex (INVALID rays are not traced); shadeNextFinish
+// then builds its queue record.
+TRT_HD inline bool shadeNextDecide(ShadeCtx& c, int max_depth, NextPlan& pl)
 {
+    pl.kind = 0; pl.u_phi = 0.0f; pl.u_theta = 0.0f;
     if (!c.shade_ok) return false;
     const bool last = (max_depth > 0 && (int)c.depth + 1 >= max_depth) || c.depth + 1 >= TRT_MAX_PATH_DEPTH;
     if (last || !(c.rng.next() < TRT_P_RR)) return false;  // RR, pathTracing.cpp:104-109
+    pl = nextRayDecide(*c.m, c.vx.pn, c.d, c.rng);
+    return pl.kind != 0;
+}
+TRT_HD inline void shadeNextFinish(const ShadeCtx& c, const NextPlan& pl, f4& ra, f4& rb, f4& bt)
+{
     f3 nd;
-    const int type = nextRay(*c.m, c.vx.pn, c.d, c.rng, nd);
-    if (type == TRT_RAY_INVALID) return false;
+    const int type = nextRayFinish(*c.m, c.vx.pn, c.d, pl, nd);
     const f3 w = (type == TRT_RAY_TRANSMISSION) ? ld3(c.m->Tr) : c.vx.Kd;  // Q8: SPECULAR is weighted by Kd too
     const f3 nb = (c.beta * w) / TRT_P_RR;
     const f3 org = rayOrigin(c, nd);  // Q6: the hit point itself unless TRT_FLAG_RAY_OFFSET
     ra = mk4(org.x, org.y, org.z, nd.x);
     rb = mk4(nd.y, nd.z, u2f(c.pid), u2f(packMeta(c.rng.ctr, (uint32_t)type, c.depth + 1)));
     bt = mk4(nb.x, nb.y, nb.z, 0.0f);
+}
+TRT_HD inline bool shadeNext(ShadeCtx& c, int max_depth, f4& ra, f4& rb, f4& bt)
+{
+    NextPlan pl;
+    if (!shadeNextDecide(c, max_depth, pl)) return false;
+    shadeNextFinish(c, pl, ra, rb, bt);
     return true;
 }
 
