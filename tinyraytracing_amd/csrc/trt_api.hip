@@ -78,6 +78,8 @@ struct trt_handle {
     uint32_t depth = 0;       // stack entries a traversal can need (wide tree), + 1
     uint32_t bvh2_depth = 0;  // depth of the caller's BVH2
     uint32_t shade_tabs = 0;  // which k_shade<TABS> this scene runs
+    const void* lds_image = nullptr;  // the tables of shade_tabs, packed
+    uint32_t lds_image_bytes = 0;
     uint32_t lds_tab[5] = {0, 0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles / (tiny scenes) shading triangles that k_shade stages in LDS
     int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
     int node_kind = 0;        // what the per-lane traversal walks: 0 exact 128-B wide nodes, 1 compressed 64-B nodes (trt_path.h CNode)
@@ -489,6 +491,25 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         h->shade_tabs = 0;
         for (uint32_t m : {31u, 15u, 7u, 3u})
             if ((have & m) == m) { h->shade_tabs = m; break; }
+        // the staged tables once more, packed in LDS layout: a block fetches them with one coalesced pass
+        const void* src[5] = {h->sc.materials, h->sc.lights, h->sc.light_cum, h->sc.light_tris, h->sc.tri_shade};
+        size_t total = 0;
+        for (int k = 0; k < 5; ++k)
+            if (h->shade_tabs >> k & 1u) total += (h->lds_tab[k] + 15u) & ~15u;
+        if (total) {
+            void* img = nullptr;
+            HIPC(hipMalloc(&img, total));
+            h->scene_allocs.push_back(img);
+            size_t off = 0;
+            for (int k = 0; k < 5; ++k)
+                if (h->shade_tabs >> k & 1u) {
+                    const size_t padded = (h->lds_tab[k] + 15u) & ~15u;  // upload() padded the source the same way
+                    HIPC(hipMemcpy((char*)img + off, src[k], padded, hipMemcpyDeviceToDevice));
+                    off += padded;
+                }
+            h->lds_image = img;
+            h->lds_image_bytes = (uint32_t)total;
+        }
     }
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
@@ -722,6 +743,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         A.lds_cum_bytes = h->lds_tab[2];
         A.lds_ltri_bytes = h->lds_tab[3];
         A.lds_tshade_bytes = h->lds_tab[4];
+        A.lds_image = (const f4*)h->lds_image;
+        A.lds_image_words = h->lds_image_bytes / 16u;
         A.stats = d_stats;
         tm.begin(TRT_K_SHADE, S.stream);
         {

@@ -662,6 +662,8 @@ struct ShadeArgs {
     // material / light / CDF / light-triangle look-ups then cost an LDS access instead of a dependent
     // global round trip each.
     uint32_t lds_mat_bytes, lds_light_bytes, lds_cum_bytes, lds_ltri_bytes, lds_tshade_bytes;
+    const f4* lds_image;      // the tables of TABS, each padded to 16 B, packed in that order
+    uint32_t lds_image_words;
     DeviceStats* stats;
 };
 
@@ -678,40 +680,50 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
     __shared__ uint32_t s_shaded, s_anyhit;
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[TABS ? TRT_SHADE_LDS_TABLE_BYTES / 4 : 4];
     if (threadIdx.x == 0) { s_shaded = 0; s_anyhit = 0; }
-    {   // stage the tables (16-byte words, coalesced), then point this block's scene view at them
+    {   // this block's view of the staged tables: the copy itself happens in the first tile, next to that tile's own loads
         uint32_t off = 0;
-        auto stage = [&](const void* src, uint32_t bytes) -> const void* {
-            const f4* g = reinterpret_cast<const f4*>(src);
-            f4* l = reinterpret_cast<f4*>(s_tab + off / 4);
-            for (uint32_t w = threadIdx.x; w < (bytes + 15u) / 16u; w += TRT_SHADE_BLOCK) l[w] = g[w];
-            off += (bytes + 15u) & ~15u;
-            return l;
-        };
-        if (TABS & 1u) sc.materials = static_cast<const MaterialDev*>(stage(sc.materials, A.lds_mat_bytes));
-        if (TABS & 2u) sc.lights = static_cast<const LightDev*>(stage(sc.lights, A.lds_light_bytes));
-        if (TABS & 4u) sc.light_cum = static_cast<const float*>(stage(sc.light_cum, A.lds_cum_bytes));
-        if (TABS & 8u) sc.light_tris = static_cast<const LightTriDev*>(stage(sc.light_tris, A.lds_ltri_bytes));
-        if (TABS & 16u) sc.tri_shade = static_cast<const TriShade*>(stage(sc.tri_shade, A.lds_tshade_bytes));
+        auto at = [&](uint32_t bytes) -> const void* { const void* q = s_tab + off / 4; off += (bytes + 15u) & ~15u; return q; };
+        if (TABS & 1u) sc.materials = static_cast<const MaterialDev*>(at(A.lds_mat_bytes));
+        if (TABS & 2u) sc.lights = static_cast<const LightDev*>(at(A.lds_light_bytes));
+        if (TABS & 4u) sc.light_cum = static_cast<const float*>(at(A.lds_cum_bytes));
+        if (TABS & 8u) sc.light_tris = static_cast<const LightTriDev*>(at(A.lds_ltri_bytes));
+        if (TABS & 16u) sc.tri_shade = static_cast<const TriShade*>(at(A.lds_tshade_bytes));
     }
-    __syncthreads();
+    bool staged = TABS == 0u;
     int parity = 0;
     uint32_t bounce_depth = 0;
     const uint32_t per_grid = gridDim.x * TRT_SHADE_BLOCK;
     // uniform trip count per block: every thread reaches every barrier
     for (uint32_t base = blockIdx.x * TRT_SHADE_BLOCK; base < A.n; base += per_grid) {
         const uint32_t i = base + threadIdx.x;
+        // Everything this vertex reads from the queues is requested at once, ahead of the first use (and, in a block's
+        // first tile, together with the scene tables): one memory round trip instead of hit -> ray -> ... in a chain.
+        f4 hit4 = mk4(TRT_INF, u2f(0xFFFFFFFFu), 0.0f, 0.0f), ra = mk4(0, 0, 0, 0), rb = ra, bt = mk4(1.0f, 1.0f, 1.0f, 0.0f);
+        if (i < A.n) {
+            hit4 = A.hit[i];
+            if (!A.primary) { ra = A.qin.ra[i]; rb = A.qin.rb[i]; bt = A.qin.bt[i]; }
+        }
+        if (!staged) {
+            // the staged tables lie packed, in LDS layout, in one device buffer (trt_create): 16-byte words, coalesced
+            f4* l = reinterpret_cast<f4*>(s_tab);
+            for (uint32_t w = threadIdx.x; w < A.lds_image_words; w += TRT_SHADE_BLOCK) l[w] = A.lds_image[w];
+            __syncthreads();
+            staged = true;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(hit4.x), "+v"(ra.x), "+v"(rb.x), "+v"(bt.x));  // keeps the four loads up here (the compiler would sink them behind the miss test)
+#endif
         ShadeCtx c;
         c.had_hit = c.shade_ok = c.add_L = false;
         if (i < A.n) {
             if (A.primary) {
                 // every path passes here exactly once, hit or miss: L starts at 0 (+ the radiance of a directly
                 // visible light, pathTracing.cpp:9-12 through main.cpp:101)
-                f4 ra, rb;
                 primaryRay(sc, A.td, A.s0, i, ra, rb);
-                shadeBegin(sc, A.td, A.s0, ra, rb, mk4(1.0f, 1.0f, 1.0f, 0.0f), A.hit[i], c);
+                shadeBegin(sc, A.td, A.s0, ra, rb, bt, hit4, c);
                 A.Lacc[i] = c.add_L ? mk4(0.0f + c.addL.x, 0.0f + c.addL.y, 0.0f + c.addL.z, 0.0f) : mk4(0.0f, 0.0f, 0.0f, 0.0f);
             } else {
-                shadeBegin(sc, A.td, A.s0, A.qin.ra[i], A.qin.rb[i], A.qin.bt[i], A.hit[i], c);
+                shadeBegin(sc, A.td, A.s0, ra, rb, bt, hit4, c);
                 if (c.add_L) {
                     f4 L = A.Lacc[c.pid];
                     L.x = L.x + c.addL.x; L.y = L.y + c.addL.y; L.z = L.z + c.addL.z;
