@@ -47,6 +47,11 @@ constexpr uint32_t COUNT_ROW = 16;                                // counters pe
 // counters k_shade bumps in one launch lie 16 KiB apart (different L2 channels: the atomic units work in
 // parallel) instead of in one cache line.
 constexpr uint32_t COUNT_STRIDE = (MAX_BOUNCES + 2 + 1023u) & ~1023u;
+// Rows PAIR_ROW and PAIR_ROW + 1 hold, as one 64-bit word per bounce b, the two counters k_shade reserves with one atomic:
+// low word = length of the queue of bounce b + 1, high word = shadow rays of the last light at bounce b.
+constexpr uint32_t PAIR_ROW = COUNT_ROW - 2;
+static_assert(1 + TRT_MAX_LIGHTS <= (int)PAIR_ROW, "counter rows overlap");
+inline unsigned long long* pairCounter(uint32_t* d_counts, uint32_t b) { return reinterpret_cast<unsigned long long*>(d_counts + (size_t)PAIR_ROW * COUNT_STRIDE) + b; }
 constexpr uint32_t MAX_BVH_DEPTH = 256;
 
 struct DevBuf {
@@ -730,7 +735,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         A.n = S.n_active;
         A.qout = S.Q[S.cur ^ 1];
         for (int l = 0; l < TRT_MAX_LIGHTS; ++l) A.sq[l] = S.SQ[l];
-        A.next_count = S.d_counts + (size_t)(S.b + 1);
+        A.pair_count = pairCounter(S.d_counts, S.b);
         A.shadow_counts = S.d_counts + (size_t)COUNT_STRIDE + S.b;  // light l: + l * COUNT_STRIDE
         A.shadow_count_stride = COUNT_STRIDE;
         A.Lacc = S.Lacc;
@@ -761,7 +766,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         st.launches[TRT_K_SHADE]++;
         // (b, c) and (b + 1, c) of the counters in use -> host_counts[2 * c], [2 * c + 1], then the sequence word
         S.seq++;
-        hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, S.stream, S.d_counts, COUNT_STRIDE, S.b, 1u + nl, (volatile uint32_t*)S.host_counts, S.seq);
+        hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, S.stream, S.d_counts, COUNT_STRIDE, S.b, 1u + nl, pairCounter(S.d_counts, S.b),
+                           (volatile uint32_t*)S.host_counts, S.seq);
         S.state = PassSlot::WAIT;
         if (h->fail_at_bounce >= 0 && (int)S.b == h->fail_at_bounce) {  // test hook: fail with this bounce's kernels in flight
             h->fail_at_bounce = -1;

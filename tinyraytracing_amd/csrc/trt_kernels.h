@@ -640,6 +640,35 @@ __device__ inline uint32_t* blockStage(bool flag, uint32_t* counter, uint32_t* s
     return s;
 }
 
+// Two queues reserved by ONE 64-bit atomic (low word: queue a, high word: queue b): the counters of the last light's
+// shadow queue and of the next bounce's queue share an 8-byte word, so a tile costs one atomic and one barrier less —
+// the atomic unit takes the reservations of one address one after the other, and k_shade's blocks reach them in bursts.
+// s2: NW offsets of a, base of a, NW offsets of b, base of b.  Same protocol as blockStage: the previous stage's base is
+// published before the barrier, this stage's atomic is issued behind it and its result (`base`, thread 0) is consumed later.
+template <int BLOCK>
+__device__ inline void blockStage2(bool fa, bool fb, unsigned long long* counter, uint32_t* s2, uint32_t& rank_a, uint32_t& rank_b,
+                                   const uint32_t* pend_s, uint32_t pend_base, unsigned long long& base)
+{
+    constexpr int NW = BLOCK / 64;
+    const unsigned long long ba = __ballot(fa), bb = __ballot(fb);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    rank_a = (uint32_t)__popcll(ba & below);
+    rank_b = (uint32_t)__popcll(bb & below);
+    if (lane == 0) { s2[wave] = (uint32_t)__popcll(ba); s2[NW + 1 + wave] = (uint32_t)__popcll(bb); }
+    if (threadIdx.x == 0 && pend_s) const_cast<uint32_t*>(pend_s)[NW] = pend_base;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ta = 0, tb = 0;
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t ca = s2[w], cb = s2[NW + 1 + w];
+            s2[w] = ta; ta += ca;
+            s2[NW + 1 + w] = tb; tb += cb;
+        }
+        base = (ta | tb) ? atomicAdd(counter, ((unsigned long long)tb << 32) | ta) : 0ull;
+    }
+}
+
 // ---------------------------------------------------------------- K3 ----
 // shade() for one path vertex (pathTracing.cpp:3-102) in its iterative form:
 // emissive early-out with the Q9 rules, vertex set-up, one NEE sample per light
@@ -650,8 +679,8 @@ struct ShadeArgs {
     uint32_t n;
     RayQueue qout;
     ShadowQueue sq[TRT_MAX_LIGHTS];
-    uint32_t* next_count;     // survivors -> qout
-    uint32_t* shadow_counts;  // light l: shadow_counts[l * shadow_count_stride]
+    unsigned long long* pair_count;  // low word: survivors -> qout, high word: shadow rays of the LAST light (one reservation for both)
+    uint32_t* shadow_counts;  // light l < n_lights - 1: shadow_counts[l * shadow_count_stride]
     uint32_t shadow_count_stride;
     f4* Lacc;
     TileDesc td;
@@ -677,6 +706,7 @@ template <uint32_t TABS>
 __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
 {
     __shared__ uint32_t s_cnt[3 * (TRT_SHADE_BLOCK / 64 + 1)];
+    __shared__ uint32_t s_cnt2[2 * (2 * (TRT_SHADE_BLOCK / 64) + 2)];  // blockStage2, two buffers used in turn
     __shared__ uint32_t s_shaded, s_anyhit;
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[TABS ? TRT_SHADE_LDS_TABLE_BYTES / 4 : 4];
     if (threadIdx.x == 0) { s_shaded = 0; s_anyhit = 0; }
@@ -690,7 +720,7 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         if (TABS & 16u) sc.tri_shade = static_cast<const TriShade*>(at(A.lds_tshade_bytes));
     }
     bool staged = TABS == 0u;
-    int parity = 0;
+    int parity = 0, parity2 = 0;
     uint32_t bounce_depth = 0;
     const uint32_t per_grid = gridDim.x * TRT_SHADE_BLOCK;
     // uniform trip count per block: every thread reaches every barrier
@@ -747,7 +777,8 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         uint32_t pend_rank = 0, pend_li = 0;
         f3 pend_wo = mk3(0, 0, 0), pend_w = mk3(0, 0, 0);
         float pend_tmax = TRT_INF;  // TRT_FLAG_FIXED_NEE: how far the occlusion test of the shadow ray reaches
-        for (uint32_t li = 0; li < sc.n_lights; ++li) {
+        const uint32_t nl = sc.n_lights;
+        for (uint32_t li = 0; li + 1 < nl; ++li) {  // every light but the last: a stage of its own
             bool emit = false;
             f3 wo = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
             float t_max = TRT_INF;
@@ -764,28 +795,49 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             }
             pend_s = s; pend_emit = emit; pend_rank = rank; pend_li = li; pend_wo = wo; pend_w = c.beta * contrib; pend_tmax = t_max;
         }
-        // The extension ray in two halves around its reservation: the decision (RR, lobe draws) before the barrier, the
-        // direction (Sample / refract: the long part) behind the atomic, whose round trip it covers.  All ray stores of
-        // the last two stages come after the last barrier: a wave that has stores in flight when it needs an atomic's
-        // result waits for vmcnt(0), i.e. for the stores as well, and the block waits for that wave.
+        // Last stage: the last light's NEE sample AND the extension ray, reserved together (blockStage2).  The extension
+        // ray comes in two halves around the reservation: the decision (RR, lobe draws) before the barrier, the direction
+        // (Sample / refract: the long part) behind the atomic, whose round trip it covers.  The rays of this stage are
+        // stored after the last barrier: a wave that has stores in flight when it needs an atomic's result waits for
+        // vmcnt(0), i.e. for the stores as well, and the block waits for that wave.
+        bool emit_s = false;
+        f3 wo_s = mk3(0, 0, 0), w_s = mk3(0, 0, 0);
+        float tmax_s = TRT_INF;
+        if (nl && c.shade_ok) {
+            f3 contrib = mk3(0, 0, 0);
+            emit_s = lightSample(sc, c.vx, *c.m, nl - 1u, c.rng, wo_s, contrib, A.td.fixed_nee != 0u, tmax_s);
+            w_s = c.beta * contrib;
+        }
         NextPlan plan;
         const bool emit_next = shadeNextDecide(c, A.max_depth, plan);
-        uint32_t rank_next;
-        uint32_t* s_next = blockStage<TRT_SHADE_BLOCK>(emit_next, A.next_count, s_cnt, parity, rank_next, pend_s, pend_base);
-        parity = parity == 2 ? 0 : parity + 1;
-        f4 nra = mk4(0, 0, 0, 0), nrb = nra, nbt = nra;
-        if (emit_next) shadeNextFinish(c, plan, nra, nrb, nbt);
-        if (threadIdx.x == 0) s_next[TRT_SHADE_BLOCK / 64] = pend_base;  // publish the last base
-        __syncthreads();
-        if (pend_emit) {
+        uint32_t rank_next, rank_s;
+        unsigned long long pair_base = 0;  // thread 0
+        uint32_t* s2 = s_cnt2 + parity2 * (2 * (TRT_SHADE_BLOCK / 64) + 2);
+        parity2 ^= 1;
+        blockStage2<TRT_SHADE_BLOCK>(emit_next, emit_s, A.pair_count, s2, rank_next, rank_s, pend_s, pend_base, pair_base);
+        if (pend_emit) {  // the last light but one (its base was published before the barrier above)
             const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
             const f3 so = rayOrigin(c, pend_wo);
             A.sq[pend_li].sa[slot] = mk4(so.x, so.y, so.z, pend_wo.x);
             A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
             A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
         }
+        f4 nra = mk4(0, 0, 0, 0), nrb = nra, nbt = nra;
+        if (emit_next) shadeNextFinish(c, plan, nra, nrb, nbt);
+        if (threadIdx.x == 0) {  // publish both bases
+            s2[TRT_SHADE_BLOCK / 64] = (uint32_t)pair_base;
+            s2[2 * (TRT_SHADE_BLOCK / 64) + 1] = (uint32_t)(pair_base >> 32);
+        }
+        __syncthreads();
+        if (emit_s) {
+            const uint32_t slot = s2[2 * (TRT_SHADE_BLOCK / 64) + 1] + s2[TRT_SHADE_BLOCK / 64 + 1 + (threadIdx.x >> 6)] + rank_s;
+            const f3 so = rayOrigin(c, wo_s);
+            A.sq[nl - 1u].sa[slot] = mk4(so.x, so.y, so.z, wo_s.x);
+            A.sq[nl - 1u].sb[slot] = mk4(wo_s.y, wo_s.z, u2f(c.pid), tmax_s);
+            A.sq[nl - 1u].sw[slot] = mk4(w_s.x, w_s.y, w_s.z, 0.0f);
+        }
         if (emit_next) {
-            const uint32_t slot = s_next[TRT_SHADE_BLOCK / 64] + s_next[threadIdx.x >> 6] + rank_next;
+            const uint32_t slot = s2[TRT_SHADE_BLOCK / 64] + s2[threadIdx.x >> 6] + rank_next;
             A.qout.ra[slot] = nra;
             A.qout.rb[slot] = nrb;
             A.qout.bt[slot] = nbt;
@@ -924,10 +976,17 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ acc
 // device-visible host buffer (out[2c], out[2c+1]), then a sequence number — the host spins on that word instead of
 // paying a DMA copy plus a stream-synchronise wake-up per bounce (one wave, launched behind k_shade).
 __global__ __launch_bounds__(64) void k_publish_counts(const uint32_t* __restrict__ counts, uint32_t stride, uint32_t b, uint32_t n,
-                                                        volatile uint32_t* out, uint32_t seq)
+                                                        const unsigned long long* __restrict__ pair, volatile uint32_t* out, uint32_t seq)
 {
     const uint32_t t = threadIdx.x;
-    if (t < 2u * n) out[t] = counts[(size_t)(t >> 1) * stride + b + (t & 1u)];
+    if (t < 2u * n) {
+        const uint32_t c = t >> 1, which = t & 1u;
+        uint32_t v = counts[(size_t)c * stride + b + which];
+        // the two counters k_shade keeps in one word (ShadeArgs::pair_count): queue length of bounce b + 1, shadow rays of the last light
+        if (c == 0u && which == 1u) v = (uint32_t)pair[0];
+        if (n > 1u && c == n - 1u && which == 0u) v = (uint32_t)(pair[0] >> 32);
+        out[t] = v;
+    }
     __threadfence_system();
     __syncthreads();
     if (t == 0) {
