@@ -750,6 +750,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         A.lds_tshade_bytes = h->lds_tab[4];
         A.lds_image = (const f4*)h->lds_image;
         A.lds_image_words = h->lds_image_bytes / 16u;
+        A.rows_lds = (rows.size() <= TRT_SHADE_ROWS_LDS && p->height <= 65536) ? (uint32_t)rows.size() : 0u;
         A.stats = d_stats;
         tm.begin(TRT_K_SHADE, S.stream);
         {

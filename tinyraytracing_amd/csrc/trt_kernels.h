@@ -47,6 +47,9 @@ constexpr int TRT_LDS_STACK_MAX = TRT_LDS_STACK_MAX_LEVELS;   // deepest LDS sta
 #ifndef TRT_SHADE_MINWAVES
 #define TRT_SHADE_MINWAVES 0
 #endif
+#ifndef TRT_SHADE_PIPE
+#define TRT_SHADE_PIPE 0
+#endif
 #if TRT_SHADE_MINWAVES > 0
 #define TRT_SHADE_BOUNDS __launch_bounds__(TRT_SHADE_BLOCK_THREADS, TRT_SHADE_MINWAVES)
 #else
@@ -693,10 +696,33 @@ struct ShadeArgs {
     uint32_t lds_mat_bytes, lds_light_bytes, lds_cum_bytes, lds_ltri_bytes, lds_tshade_bytes;
     const f4* lds_image;      // the tables of TABS, each padded to 16 B, packed in that order
     uint32_t lds_image_words;
+    uint32_t rows_lds;        // number of rows of td.rows to keep in LDS as 16-bit values (0: the tile has more than TRT_SHADE_ROWS_LDS rows, or rows >= 65536)
     DeviceStats* stats;
 };
 
 constexpr uint32_t TRT_SHADE_LDS_TABLE_BYTES = 24 * 1024;
+constexpr uint32_t TRT_SHADE_ROWS_LDS = 8192;
+
+// The tile's row table as k_shade sees it: a 16-bit copy in LDS when it fits.  The key of a path's random stream hangs on the
+// image row, i.e. on this look-up: from global memory it is a dependent load in every vertex, and — the memory counter being
+// in order — one that also waits for the queue records requested ahead for the next tile.
+struct RowsShade {
+    const uint16_t* lds;
+    bool in_lds;
+    __device__ int operator()(const TileDesc& td, uint32_t r) const
+    {
+        int y = 0;
+        if (in_lds) {
+            y = lds[r];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(y));  // keeps this a ds_read (merged with the global load below it would become a FLAT one)
+#endif
+        } else {
+            y = td.rows[r];
+        }
+        return y;
+    }
+};
 
 // TABS: bit k set = table k (materials, lights, light CDF, light triangles, shading triangles) is staged in LDS by this
 // instantiation.  A compile-time choice so that every table access is a plain LDS (ds_read) or global load: behind a
@@ -709,7 +735,13 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
     __shared__ uint32_t s_cnt2[2 * (2 * (TRT_SHADE_BLOCK / 64) + 2)];  // blockStage2, two buffers used in turn
     __shared__ uint32_t s_shaded, s_anyhit;
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[TABS ? TRT_SHADE_LDS_TABLE_BYTES / 4 : 4];
+    __shared__ uint16_t s_rows[TRT_SHADE_ROWS_LDS];
     if (threadIdx.x == 0) { s_shaded = 0; s_anyhit = 0; }
+    for (uint32_t r = threadIdx.x; r < A.rows_lds; r += TRT_SHADE_BLOCK) s_rows[r] = (uint16_t)A.td.rows[r];
+    RowsShade rows;
+    rows.lds = s_rows;
+    rows.in_lds = A.rows_lds != 0u;
+    bool rows_visible = A.rows_lds == 0u;  // the copy above is visible to the block (a barrier lies in between)
     {   // this block's view of the staged tables: the copy itself happens in the first tile, next to that tile's own loads
         uint32_t off = 0;
         auto at = [&](uint32_t bytes) -> const void* { const void* q = s_tab + off / 4; off += (bytes + 15u) & ~15u; return q; };
@@ -724,24 +756,43 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
     uint32_t bounce_depth = 0;
     const uint32_t per_grid = gridDim.x * TRT_SHADE_BLOCK;
     // uniform trip count per block: every thread reaches every barrier
-    for (uint32_t base = blockIdx.x * TRT_SHADE_BLOCK; base < A.n; base += per_grid) {
-        const uint32_t i = base + threadIdx.x;
-        // Everything this vertex reads from the queues is requested at once, ahead of the first use (and, in a block's
-        // first tile, together with the scene tables): one memory round trip instead of hit -> ray -> ... in a chain.
-        f4 hit4 = mk4(TRT_INF, u2f(0xFFFFFFFFu), 0.0f, 0.0f), ra = mk4(0, 0, 0, 0), rb = ra, bt = mk4(1.0f, 1.0f, 1.0f, 0.0f);
+    // Everything a vertex reads from the queues is requested at once (one memory round trip instead of hit -> ray -> ...
+    // in a chain) and one tile AHEAD (TRT_SHADE_PIPE): the records of the block's next tile are in flight while this tile
+    // is computed, so a tile starts on data that has already arrived.
+    auto loadTile = [&](uint32_t i, f4& hit4, f4& ra, f4& rb, f4& bt) {
+        hit4 = mk4(TRT_INF, u2f(0xFFFFFFFFu), 0.0f, 0.0f); ra = mk4(0, 0, 0, 0); rb = ra; bt = mk4(1.0f, 1.0f, 1.0f, 0.0f);
         if (i < A.n) {
             hit4 = A.hit[i];
             if (!A.primary) { ra = A.qin.ra[i]; rb = A.qin.rb[i]; bt = A.qin.bt[i]; }
         }
-        if (!staged) {
+    };
+#if TRT_SHADE_PIPE
+    f4 n_hit, n_ra, n_rb, n_bt;
+    loadTile(blockIdx.x * TRT_SHADE_BLOCK + threadIdx.x, n_hit, n_ra, n_rb, n_bt);
+#endif
+    for (uint32_t base = blockIdx.x * TRT_SHADE_BLOCK; base < A.n; base += per_grid) {
+        const uint32_t i = base + threadIdx.x;
+        f4 hit4, ra, rb, bt;
+#if TRT_SHADE_PIPE
+        hit4 = n_hit; ra = n_ra; rb = n_rb; bt = n_bt;
+#else
+        loadTile(i, hit4, ra, rb, bt);
+#endif
+        if (!staged || !rows_visible) {
             // the staged tables lie packed, in LDS layout, in one device buffer (trt_create): 16-byte words, coalesced
-            f4* l = reinterpret_cast<f4*>(s_tab);
-            for (uint32_t w = threadIdx.x; w < A.lds_image_words; w += TRT_SHADE_BLOCK) l[w] = A.lds_image[w];
+            if (!staged) {
+                f4* l = reinterpret_cast<f4*>(s_tab);
+                for (uint32_t w = threadIdx.x; w < A.lds_image_words; w += TRT_SHADE_BLOCK) l[w] = A.lds_image[w];
+            }
             __syncthreads();
             staged = true;
+            rows_visible = true;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(hit4.x), "+v"(ra.x), "+v"(rb.x), "+v"(bt.x));  // keeps the four loads up here (the compiler would sink them behind the miss test)
+#endif
+#if TRT_SHADE_PIPE
+        loadTile(i + per_grid, n_hit, n_ra, n_rb, n_bt);  // n <= 0x7FFF0000 and per_grid <= 2^25: no wrap-around
 #endif
         ShadeCtx c;
         c.had_hit = c.shade_ok = c.add_L = false;
@@ -749,11 +800,11 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             if (A.primary) {
                 // every path passes here exactly once, hit or miss: L starts at 0 (+ the radiance of a directly
                 // visible light, pathTracing.cpp:9-12 through main.cpp:101)
-                primaryRay(sc, A.td, A.s0, i, ra, rb);
-                shadeBegin(sc, A.td, A.s0, ra, rb, bt, hit4, c);
+                primaryRay(sc, A.td, A.s0, i, ra, rb, rows);
+                shadeBegin(sc, A.td, A.s0, ra, rb, bt, hit4, c, rows);
                 A.Lacc[i] = c.add_L ? mk4(0.0f + c.addL.x, 0.0f + c.addL.y, 0.0f + c.addL.z, 0.0f) : mk4(0.0f, 0.0f, 0.0f, 0.0f);
             } else {
-                shadeBegin(sc, A.td, A.s0, ra, rb, bt, hit4, c);
+                shadeBegin(sc, A.td, A.s0, ra, rb, bt, hit4, c, rows);
                 if (c.add_L) {
                     f4 L = A.Lacc[c.pid];
                     L.x = L.x + c.addL.x; L.y = L.y + c.addL.y; L.z = L.z + c.addL.z;

@@ -733,23 +733,31 @@ struct TileDesc {
     uint32_t seed, spp;
 };
 
+// Image row of packed row r of the tile: the table in global memory.  k_shade passes a look-up of its own (an LDS copy of
+// the table: a dependent global load per vertex otherwise).
+struct RowsGlobal {
+    TRT_HD int operator()(const TileDesc& td, uint32_t r) const { return td.rows[r]; }
+};
+
 // path id -> (pixel index y*W+x, sample index): id = s_local * npix + pixel-in-tile
-TRT_HD inline trt_rng_key pathKey(const TileDesc& td, uint32_t s0, uint32_t pid)
+template <class Rows = RowsGlobal>
+TRT_HD inline trt_rng_key pathKey(const TileDesc& td, uint32_t s0, uint32_t pid, Rows rows = Rows())
 {
     const uint32_t s_local = pid / td.npix, pl = pid - s_local * td.npix;
     const uint32_t r = pl / (uint32_t)td.tile_w, c = pl - r * (uint32_t)td.tile_w;
-    const uint32_t pixel = (uint32_t)td.rows[r] * (uint32_t)td.width + (uint32_t)(td.x0 + (int)c);
+    const uint32_t pixel = (uint32_t)rows(td, r) * (uint32_t)td.width + (uint32_t)(td.x0 + (int)c);
     return trt_rng_make_key(td.seed, pixel, s0 + s_local);
 }
 
 // The camera ray of path `pid` (main.cpp:88-95, camera.cpp:19-28) as the queue record (ra, rb): a pure
 // function of the path id, so bounce 0 never goes through HBM — the traversal kernel generates it and
 // k_shade generates the same bits again.
-TRT_HD inline void primaryRay(const SceneDev& sc, const TileDesc& td, uint32_t s0, uint32_t pid, f4& ra, f4& rb)
+template <class Rows = RowsGlobal>
+TRT_HD inline void primaryRay(const SceneDev& sc, const TileDesc& td, uint32_t s0, uint32_t pid, f4& ra, f4& rb, Rows rows = Rows())
 {
     const uint32_t s_local = pid / td.npix, pl = pid - s_local * td.npix;
     const uint32_t r = pl / (uint32_t)td.tile_w, c = pl - r * (uint32_t)td.tile_w;
-    const int y = td.rows[r], x = td.x0 + (int)c;
+    const int y = rows(td, r), x = td.x0 + (int)c;
     Stream rng;
     rng.key = trt_rng_make_key(td.seed, (uint32_t)y * (uint32_t)td.width + (uint32_t)x, s0 + s_local);
     rng.ctr = 0;
@@ -791,7 +799,8 @@ TRT_HD inline f3 rayOrigin(const ShadeCtx& c, f3 w)
 }
 
 // First part of shade() (pathTracing.cpp:9-30) for the ray (ra, rb, bt) and its hit record.
-TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s0, const f4& ra, const f4& rb, const f4& bt, const f4& hit4, ShadeCtx& c)
+template <class Rows = RowsGlobal>
+TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s0, const f4& ra, const f4& rb, const f4& bt, const f4& hit4, ShadeCtx& c, Rows rows = Rows())
 {
     c.had_hit = c.shade_ok = c.add_L = false;
     c.addL = mk3(0, 0, 0);
@@ -830,7 +839,7 @@ TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s
     c.shade_ok = true;
     c.vx = makeVertex(sc, h, o, c.d, ts, *c.m);
     if (c.use_off) c.off = offsetVector(sc.tri_isect[h.tri], c.vx.P);
-    c.rng.key = pathKey(td, s0, c.pid);
+    c.rng.key = pathKey(td, s0, c.pid, rows);
     c.rng.ctr = metaCtr(meta);
 }
 

@@ -77,6 +77,46 @@ __global__ __launch_bounds__(256) void k_chase(const f4* __restrict__ table, uin
     if (acc == 123.456f) sink[gid] = acc;
 }
 
+
+// Wave-cooperative fetch of 64 per-lane records (what a wide-node visit of 64 divergent rays needs): in load k, lane j
+// requests 16-B piece (j & 7) of the record owned by lane 8 k + (j >> 3), so eight neighbouring lanes cover one 128-B line
+// and the load is as coalesced as the hardware can see; the pieces go through LDS ([owner][piece], 112-B stride: conflict
+// free for b128) to their owners.  PIECES = 7 (a WideNode).  `chase`: the next record index depends on the data.
+__global__ __launch_bounds__(256) void k_coop(const f4* __restrict__ table, uint32_t n_records, uint32_t iters, uint32_t chase, float* __restrict__ sink)
+{
+    __shared__ f4 stage[4][64 * 7 + 8];  // + a dump for the eighth lane of every group (no branch around the loads)
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    f4* st = stage[wave];
+    const uint32_t piece = lane & 7u, sub = lane >> 3;
+    uint32_t rec = mix32(gid) % n_records;
+    float acc = 0.f;
+    for (uint32_t it = 0; it < iters; ++it) {
+        f4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t r = (uint32_t)__shfl((int)rec, 8 * k + (int)sub);
+            v[k] = table[(size_t)r * 8 + (piece < 7u ? piece : 6u)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[piece < 7u ? (8 * k + sub) * 7 + piece : 64 * 7 + sub] = v[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t nxt = 0;
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            const f4 w = st[lane * 7 + p];
+            acc += w.x;
+            nxt ^= __float_as_uint(w.w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        rec = chase ? mix32(nxt + gid + it) % n_records : mix32(gid * 0x9E3779B9u + it * 0x85EBCA6Bu) % n_records;
+    }
+    if (acc == 123.456f) sink[gid] = acc;
+}
+
 template <int LOADS>
 __global__ __launch_bounds__(256) void k_gather_lds(const f4* __restrict__ table, uint32_t n_records, uint32_t iters, uint32_t coherent, float* __restrict__ sink)
 {
@@ -212,6 +252,26 @@ int main(int argc, char** argv)
             if (sz.bytes <= ((size_t)2 << 20)) runGather(loads, sz, 1u, false);
         }
     for (const Size& sz : sizes) { runGather(4, sz, 0u, true); runGather(7, sz, 0u, true); }
+
+
+    // cooperative fetch against the per-lane gather / chase of 7 pieces, at the occupancy its LDS staging leaves (5 blocks per CU)
+    for (const Size& sz : sizes)
+        for (int mode = 0; mode < 3; ++mode) {  // 0: k_chase<7> at 5 waves/SIMD, 1: coop chase, 2: coop independent
+            char name[128];
+            std::snprintf(name, sizeof name, "%s table=%s waves/SIMD=5", mode == 0 ? "chase loads=7 (per lane)" : mode == 1 ? "coop chase pieces=7" : "coop gather pieces=7", sz.name);
+            if (only[0] && !std::strstr(name, only)) continue;
+            const uint32_t n_records = (uint32_t)(sz.bytes / 128), iters = 64, nb = (uint32_t)cus * 5;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(e0));
+                if (mode == 0) hipLaunchKernelGGL(k_chase<7>, dim3(nb), dim3(256), 0, 0, table, n_records, iters, sink);
+                else hipLaunchKernelGGL(k_coop, dim3(nb), dim3(256), 0, 0, table, n_records, iters, mode == 1 ? 1u : 0u, sink);
+                CK(hipEventRecord(e1));
+                const double ms = timeIt(e0, e1);
+                if (rep == 0) continue;
+                const double visits = (double)nb * 256 * iters;
+                std::printf("%-52s %8.3f ms  %6.3f record visits/clk/CU  (%.1f clk per visit and CU)\n", name, ms, visits / (ms * 1e-3 * clk) / cus, (ms * 1e-3 * clk) * cus / visits);
+            }
+        }
 
     for (int coherent = 0; coherent < 2; ++coherent)
         for (int loads : {4, 7}) {
