@@ -617,6 +617,25 @@ __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uin
     traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false, NK>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u);
 }
 
+
+// Block barrier for data exchanged through LDS only.  __syncthreads() also fences global memory: the compiler puts
+// s_waitcnt vmcnt(0) in front of it, i.e. every wave waits for the acknowledgement of the ray records it has just stored
+// (a trip to the L2 and, with the queues streaming at terabytes per second, well beyond) although no thread of the block ever
+// reads them.  The fences here name the LDS address space, so only lgkmcnt(0) is waited for and stores stay in flight.
+#ifndef TRT_LDS_BARRIER
+#define TRT_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void ldsBarrier()
+{
+#if TRT_LDS_BARRIER
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    __syncthreads();
+#endif
+}
+
 // Block-wide stream compaction in two halves.  blockStage: every thread calls it with its `flag`; wave
 // ranks come from __ballot/popcount, wave totals go through LDS, and after ONE barrier thread 0 turns them
 // into exclusive offsets and issues the block's single atomicAdd on the queue counter — without waiting for
@@ -634,7 +653,7 @@ __device__ inline uint32_t* blockStage(bool flag, uint32_t* counter, uint32_t* s
     rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
     if (lane == 0) s[wave] = (uint32_t)__popcll(ballot);
     if (threadIdx.x == 0 && pend_s) const_cast<uint32_t*>(pend_s)[NW] = pend_base;
-    __syncthreads();
+    ldsBarrier();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
         for (int w = 0; w < NW; ++w) { const uint32_t c = s[w]; s[w] = tot; tot += c; }
@@ -660,7 +679,7 @@ __device__ inline void blockStage2(bool fa, bool fb, unsigned long long* counter
     rank_b = (uint32_t)__popcll(bb & below);
     if (lane == 0) { s2[wave] = (uint32_t)__popcll(ba); s2[NW + 1 + wave] = (uint32_t)__popcll(bb); }
     if (threadIdx.x == 0 && pend_s) const_cast<uint32_t*>(pend_s)[NW] = pend_base;
-    __syncthreads();
+    ldsBarrier();
     if (threadIdx.x == 0) {
         uint32_t ta = 0, tb = 0;
         for (int w = 0; w < NW; ++w) {
@@ -879,7 +898,7 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             s2[TRT_SHADE_BLOCK / 64] = (uint32_t)pair_base;
             s2[2 * (TRT_SHADE_BLOCK / 64) + 1] = (uint32_t)(pair_base >> 32);
         }
-        __syncthreads();
+        ldsBarrier();
         if (emit_s) {
             const uint32_t slot = s2[2 * (TRT_SHADE_BLOCK / 64) + 1] + s2[TRT_SHADE_BLOCK / 64 + 1 + (threadIdx.x >> 6)] + rank_s;
             const f3 so = rayOrigin(c, wo_s);
