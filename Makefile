@@ -15,7 +15,11 @@ CXXFLAGS := -O2 -g0 -std=c++17 -fPIC -Wall -Wextra $(CPU_FP) -Iinclude -I$(PKG)/
 # The LLVM atomic optimizer turns the one-lane queue reservation of k_shade (blockStage) into "atomic; s_waitcnt vmcnt(0);
 # readfirstlane", i.e. waits for the round trip (and every store before it) on the spot; the kernel consumes the value one
 # stage later.  No kernel here relies on that pass: every atomic is issued by one lane per wave already.
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
+# -fno-slp-vectorize: left to itself the SLP vectoriser pairs the scalar fp32 operations of the triangle test and of the shading
+# code into v_pk_* instructions; on gfx950 a v_pk_mul/add costs what two v_mul/add cost (tools/valu_probe.hip: 4.6 against
+# 2 x 2.4 clocks per wave) and the pairs have to be assembled with v_mov first: trace_closest on `back` -9 %, k_shade -3 %.
+# (The explicit two-wide code of innerStep() is not affected: its operands are loaded as pairs.)
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -mllvm -amdgpu-atomic-optimizer-strategy=None \
             -Wall -Wextra -Wno-unused-parameter -Iinclude -I$(PKG)/csrc
 

@@ -28,6 +28,13 @@ __global__ __launch_bounds__(256) void k_issue(uint32_t iters, float* __restrict
             if (KIND == 6) asm volatile("v_rcp_f32 %0, %0\nv_rcp_f32 %1, %1\nv_rcp_f32 %2, %2\nv_rcp_f32 %3, %3\nv_rcp_f32 %4, %4\nv_rcp_f32 %5, %5\nv_rcp_f32 %6, %6\nv_rcp_f32 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
             if (KIND == 7) asm volatile("v_mul_f32 %0, %0, %8\nv_mul_f32 %1, %1, %8\nv_mul_f32 %2, %2, %8\nv_mul_f32 %3, %3, %8\nv_mul_f32 %4, %4, %8\nv_mul_f32 %5, %5, %8\nv_mul_f32 %6, %6, %8\nv_mul_f32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
             if (KIND == 8) asm volatile("v_xor_b32 %0, %0, %8\nv_xor_b32 %1, %1, %8\nv_xor_b32 %2, %2, %8\nv_xor_b32 %3, %3, %8\nv_xor_b32 %4, %4, %8\nv_xor_b32 %5, %5, %8\nv_xor_b32 %6, %6, %8\nv_xor_b32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+            if (KIND == 9) asm volatile("v_fmac_f32_e32 %0, %8, %9\nv_fmac_f32_e32 %1, %8, %9\nv_fmac_f32_e32 %2, %8, %9\nv_fmac_f32_e32 %3, %8, %9\nv_fmac_f32_e32 %4, %8, %9\nv_fmac_f32_e32 %5, %8, %9\nv_fmac_f32_e32 %6, %8, %9\nv_fmac_f32_e32 %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            if (KIND == 10) asm volatile("v_mul_f32_e64 %0, %0, -%8\nv_mul_f32_e64 %1, %1, -%8\nv_mul_f32_e64 %2, %2, -%8\nv_mul_f32_e64 %3, %3, -%8\nv_mul_f32_e64 %4, %4, -%8\nv_mul_f32_e64 %5, %5, -%8\nv_mul_f32_e64 %6, %6, -%8\nv_mul_f32_e64 %7, %7, -%8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+            if (KIND == 11) asm volatile("v_fma_f32 %0, %0, %8, %9\nv_fma_f32 %1, %1, %8, %9\nv_fma_f32 %2, %2, %8, %9\nv_fma_f32 %3, %3, %8, %9\nv_fma_f32 %4, %4, %8, %9\nv_fma_f32 %5, %5, %8, %9\nv_fma_f32 %6, %6, %8, %9\nv_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(m), "v"(c));
+            if (KIND == 12) asm volatile("v_fmac_f32_e32 %0, %8, %9\nv_fmac_f32_e32 %1, %8, %9\nv_fmac_f32_e32 %2, %8, %9\nv_fmac_f32_e32 %3, %8, %9\nv_fmac_f32_e32 %4, %8, %9\nv_fmac_f32_e32 %5, %8, %9\nv_fmac_f32_e32 %6, %8, %9\nv_fmac_f32_e32 %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(m), "v"(c));
+            if (KIND == 13) asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\nv_cndmask_b32_e32 %1, %1, %8, vcc\nv_cndmask_b32_e32 %2, %2, %8, vcc\nv_cndmask_b32_e32 %3, %3, %8, vcc\nv_cndmask_b32_e32 %4, %4, %8, vcc\nv_cndmask_b32_e32 %5, %5, %8, vcc\nv_cndmask_b32_e32 %6, %6, %8, vcc\nv_cndmask_b32_e32 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");
+            if (KIND == 14) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %8\nv_cmp_lt_f32_e32 vcc, %1, %8\nv_cmp_lt_f32_e32 vcc, %2, %8\nv_cmp_lt_f32_e32 vcc, %3, %8\nv_cmp_lt_f32_e32 vcc, %4, %8\nv_cmp_lt_f32_e32 vcc, %5, %8\nv_cmp_lt_f32_e32 vcc, %6, %8\nv_cmp_lt_f32_e32 vcc, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");
+            if (KIND == 15) asm volatile("v_min_f32_e32 %0, %0, %8\nv_max_f32_e32 %1, %1, %8\nv_min_f32_e32 %2, %2, %8\nv_max_f32_e32 %3, %3, %8\nv_min_f32_e32 %4, %4, %8\nv_max_f32_e32 %5, %5, %8\nv_min_f32_e32 %6, %6, %8\nv_max_f32_e32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
         }
     }
     const float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + (p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y);
@@ -47,10 +54,10 @@ int main()
     CK(hipEventCreate(&e1));
     float* sink = nullptr;
     CK(hipMalloc(&sink, (size_t)1 << 24));
-    const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_cmp+v_cndmask", "v_max3_f32", "v_rcp_f32", "v_mul_f32", "v_xor_b32"};
+    const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_cmp+v_cndmask", "v_max3_f32", "v_rcp_f32", "v_mul_f32", "v_xor_b32", "v_fmac_f32_e32", "v_mul_f32_e64 (neg)", "v_fma_f32 (sgpr src)", "v_fmac_e32 (sgpr src)", "v_cndmask_e32", "v_cmp_e32", "v_min/max_f32_e32"};
     const uint32_t iters = 2048;
-    for (int kind = 0; kind < 9; ++kind)
-        for (int bpc : {1, 2, 4, 8}) {
+    for (int kind = 0; kind < 16; ++kind)
+        for (int bpc : {2, 8}) {
             float ms = 0.f;
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipEventRecord(e0));
@@ -64,7 +71,14 @@ int main()
                     case 5: hipLaunchKernelGGL(k_issue<5>, g, b, 0, 0, iters, sink); break;
                     case 6: hipLaunchKernelGGL(k_issue<6>, g, b, 0, 0, iters, sink); break;
                     case 7: hipLaunchKernelGGL(k_issue<7>, g, b, 0, 0, iters, sink); break;
-                    default: hipLaunchKernelGGL(k_issue<8>, g, b, 0, 0, iters, sink); break;
+                    case 8: hipLaunchKernelGGL(k_issue<8>, g, b, 0, 0, iters, sink); break;
+                    case 9: hipLaunchKernelGGL(k_issue<9>, g, b, 0, 0, iters, sink); break;
+                    case 10: hipLaunchKernelGGL(k_issue<10>, g, b, 0, 0, iters, sink); break;
+                    case 11: hipLaunchKernelGGL(k_issue<11>, g, b, 0, 0, iters, sink); break;
+                    case 12: hipLaunchKernelGGL(k_issue<12>, g, b, 0, 0, iters, sink); break;
+                    case 13: hipLaunchKernelGGL(k_issue<13>, g, b, 0, 0, iters, sink); break;
+                    case 14: hipLaunchKernelGGL(k_issue<14>, g, b, 0, 0, iters, sink); break;
+                    default: hipLaunchKernelGGL(k_issue<15>, g, b, 0, 0, iters, sink); break;
                 }
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
