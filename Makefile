@@ -26,10 +26,10 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fa
 HOST_SRC := $(PKG)/host/scene.cpp $(PKG)/host/bvh.cpp $(PKG)/host/synth.cpp $(PKG)/host/image_out.cpp $(PKG)/host/jpeg.cpp $(PKG)/host/capi.cpp
 HOST_HDR := $(wildcard $(PKG)/host/*.h) include/trt.h include/trt_host.h include/trt_prims.h
 HIP_SRC := $(PKG)/csrc/trt_api.hip
-HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h
+HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h include/trt_exact.h
 
-.PHONY: all host hip oracle cli hostsim variants probe clean
-all: host hip oracle hostsim cli
+.PHONY: all host hip oracle cli hostsim variants probe exactcheck clean
+all: host hip oracle hostsim cli exactcheck
 
 host: $(OUT)/libtrt_host.so
 hip: $(OUT)/libtrt_hip.so
@@ -63,6 +63,11 @@ variants: $(HIP_SRC) $(HIP_HDR)
 clean:
 	rm -rf $(OUT) tests/hostsim/libhostsim.so
 	$(MAKE) -C oracle clean
+
+# exhaustive (2^32 inputs) proof that include/trt_exact.h returns the bits of sqrtf / 1.0f / sqrtf: run by tests/test_gpu_parity.py
+exactcheck: tools/exact_unary_check
+tools/exact_unary_check: tools/exact_unary_check.hip include/trt_exact.h include/trt_prims.h
+	$(HIPCC) -O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Iinclude -o $@ tools/exact_unary_check.hip
 
 # chip-ceiling probe + TCC counter calibration workload (tools/calibrate_counters.sh runs it on the GPU box)
 probe: tools/gather_probe

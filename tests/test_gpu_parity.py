@@ -656,3 +656,17 @@ def test_ray_offset_flag_matches_oracle(name, w, h, spp, renderer_factory):
         ref, ost = O.render(s.flat, p)
         assert_same_image(img, ref, f"{name} ray offset flags={flags}")
         assert (st.rays_camera, st.rays_shadow, st.rays_indirect, st.shaded_hits) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect, ost.shaded_hits)
+
+
+@pytest.mark.gpu
+def test_exact_sqrt_sequences_equal_ieee_on_every_input():
+    """include/trt_exact.h: the short v_rsq-based sequences the kernels use for sqrtf(x) and 1.0f / sqrtf(x) return the bits of
+    hipcc's correctly rounded expansions for ALL 2^32 binary32 inputs (a unary function: the check is exhaustive, i.e. a proof).
+    The tool also checks that it really visited 2^32 inputs."""
+    import subprocess
+    exe = os.path.join(T.REPO_ROOT, "tools", "exact_unary_check")
+    assert os.path.exists(exe), "tools/exact_unary_check is not built (make exactcheck)"
+    r = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if "inputs differ" in l]
+    assert len(lines) == 4 and all(" 0 of 4294967296 inputs differ" in l for l in lines), r.stdout

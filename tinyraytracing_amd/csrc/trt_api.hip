@@ -375,6 +375,10 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     // (blob-2M, soup-1M -2.6 % per step; the cg22 scenes are 0.7 % better off with the plain majority)
     h->sc.sched_in_w = s->n_tris <= 200000u ? 1u : 2u;
     h->sc.sched_lf_w = s->n_tris <= 200000u ? 1u : 3u;
+    if (const char* e = std::getenv("TRT_SCHED_W")) {  // "in:leaf" weights of the scheduler driver (tuning)
+        unsigned a = 0, b = 0;
+        if (std::sscanf(e, "%u:%u", &a, &b) == 2 && a > 0 && b > 0 && a < 1024 && b < 1024) { h->sc.sched_in_w = a; h->sc.sched_lf_w = b; }
+    }
     if (const char* e = std::getenv("TRT_REFILL_MIN")) h->sc.refill_min = std::min(64u, std::max(1u, (uint32_t)std::strtoul(e, nullptr, 10)));
     if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: refill_min %u tail_n %u\n", h->sc.refill_min, h->tail_n);
     if (const char* e = std::getenv("TRT_TRACE_RPW")) h->rays_per_wave = (uint32_t)std::strtoul(e, nullptr, 10);

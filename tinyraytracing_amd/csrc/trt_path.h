@@ -16,6 +16,7 @@
 
 #include "trt.h"
 #include "trt_prims.h"
+#include "trt_exact.h"
 
 #ifndef TRT_PREFETCH
 #define TRT_PREFETCH 1
@@ -43,8 +44,9 @@ TRT_HD inline f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s
 // glm evaluation order: dot = (x + y) + z; normalize = v * (1 / sqrt(dot(v, v)))
 TRT_HD inline float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 TRT_HD inline f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-TRT_HD inline float length(f3 a) { return sqrtf(dot(a, a)); }
-TRT_HD inline f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+// sqrtf(x) and 1.0f / sqrtf(x) through trt_exact.h: the same bits (proven over all 2^32 inputs) in a third of the instructions
+TRT_HD inline float length(f3 a) { return trt_sqrt(dot(a, a)); }
+TRT_HD inline f3 normalize(f3 a) { return a * trt_rsqrt2(dot(a, a)); }
 // glm::reflect / glm::refract (pathTracing.cpp:177,184,202)
 TRT_HD inline f3 reflect(f3 I, f3 N) { return I - (N * dot(N, I)) * 2.0f; }
 TRT_HD inline f3 refract(f3 I, f3 N, float eta)
@@ -52,7 +54,7 @@ TRT_HD inline f3 refract(f3 I, f3 N, float eta)
     const float dn = dot(N, I);
     const float k = 1.0f - eta * eta * (1.0f - dn * dn);
     if (k < 0.0f) return mk3(0.f, 0.f, 0.f);
-    return I * eta - N * (eta * dn + sqrtf(k));
+    return I * eta - N * (eta * dn + trt_sqrt(k));
 }
 
 TRT_HD inline uint32_t f2u(float f) { return trt_f2u(f); }
@@ -279,8 +281,10 @@ TRT_HD inline bool slabResult(float inx, float iny, float inz, float outx, float
     const float t1 = fminf(fmaxf(inx, outx), fminf(fmaxf(iny, outy), fmaxf(inz, outz)));
     const float t0 = fmaxf(fminf(inx, outx), fmaxf(fminf(iny, outy), fminf(inz, outz)));
     entry = t0;
-    const float r = (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
-    return r > 0.0f;  // the caller descends iff the result is > 0 (bvh.cpp:162-166)
+    // bvh.cpp:243-244 returns r = (t1 >= t0) ? ((t0 > 0) ? t0 : t1) : -1 and the caller descends iff r > 0 (bvh.cpp:162-166).
+    // With t1 >= t0 true (so neither is NaN): t0 > 0 gives r = t0 > 0, and then t1 >= t0 > 0 as well; otherwise r = t1.  Either
+    // way r > 0 <=> t1 > 0, so the decision is (t1 >= t0) && (t1 > 0) for every input — two compares, no select.
+    return (t1 >= t0) && (t1 > 0.0f);
 }
 TRT_HD inline bool boxTest(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float& entry)
 {
@@ -527,12 +531,12 @@ TRT_HD inline f3 sampleDir(f3 a, int ray_type, float Ns, float u_phi, float u_th
     trt_sincos2pi(u_phi, &c, &s);
     float sin_t, cos_t;
     if (ray_type == TRT_RAY_DIFFUSE) {
-        sin_t = sqrtf(u_theta);
-        cos_t = sqrtf(1.0f - u_theta);
+        sin_t = trt_sqrt(u_theta);
+        cos_t = trt_sqrt(1.0f - u_theta);
     } else {
         cos_t = trt_pow01(u_theta, 1.0f / (Ns + 1.0f));
         const float s2 = 1.0f - cos_t * cos_t;
-        sin_t = sqrtf(s2 > 0.0f ? s2 : 0.0f);
+        sin_t = trt_sqrt(s2 > 0.0f ? s2 : 0.0f);
     }
     const f3 local = mk3(sin_t * c, cos_t, sin_t * s);
     f3 front;
@@ -674,7 +678,7 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
     const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
     float p1, p2, p3;
     if (fixed) {  // uniform on the triangle; r3 is drawn (same stream layout) but unused
-        const float su = sqrtf(r1);
+        const float su = trt_sqrt(r1);
         p1 = 1.0f - su; p2 = su * (1.0f - r2); p3 = su * r2;
     } else {
         const float rs = (r1 + r2) + r3;
@@ -683,10 +687,12 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
     const f3 light_p = (ld3(lt->v[0]) * p1 + ld3(lt->v[1]) * p2) + ld3(lt->v[2]) * p3;
     const f3 light_n = normalize((ld3(lt->vn[0]) * p1 + ld3(lt->vn[1]) * p2) + ld3(lt->vn[2]) * p3);
     const f3 diff = light_p - vx.P;
-    wo = normalize(diff);
+    float diff_len, diff_rlen;  // length(diff) and the factor of normalize(diff): one square root serves both
+    trt_sqrt_rsqrt2(dot(diff, diff), &diff_len, &diff_rlen);
+    wo = diff * diff_rlen;
     const float cos_s = dot(wo, vx.pn);
     if (!(cos_s > 0.0f)) return false;  // pathTracing.cpp:60: such a sample never contributes
-    t_max = (fixed ? 0.999f : 1.001f) * length(diff);
+    t_max = (fixed ? 0.999f : 1.001f) * diff_len;
     const float pdf_light = L.pdf;  // 1 / area, makeLightDev
     const float cos_theta_p = fabsf(dot(wo, light_n));
     const float cos_theta = fabsf(cos_s / length(vx.pn));
