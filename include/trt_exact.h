@@ -1,6 +1,7 @@
 /*
- * trt_exact.h — correctly rounded fp32 square root and reciprocal square root in fewer instructions than the general-purpose
- * expansions hipcc emits for `sqrtf(x)` and `1.0f / sqrtf(x)`.
+ * trt_exact.h — correctly rounded fp32 square root and reciprocal square root, and binary64 division by a divisor whose
+ * reciprocal is known, in fewer instructions than the general-purpose expansions hipcc emits for `sqrtf(x)`, `1.0f / sqrtf(x)`
+ * and `a / b`.
  *
  * The kernels are bound by VALU issue, and a path vertex normalises six vectors: glm::normalize is
  * v * (1 / sqrt(dot(v, v))) — a correctly rounded square root (15 instructions on gfx950) followed by a correctly rounded
@@ -100,6 +101,24 @@ static inline TRT_HD float trt_rsqrt2(float x)
     float s, r;
     trt_sqrt_rsqrt2(x, &s, &r);
     return r;
+}
+
+/* a / b in binary64 when the correctly rounded reciprocal rb = 1.0 / b of the divisor is at hand (the pixel grid of
+ * main.cpp:88-93 divides by W - 1, H - 1, W and H: wave-uniform, formed once per render on the host): one product, the exact
+ * residual a - q0 b in an fma, one correction — Markstein's theorem makes q the correctly rounded quotient whenever rb is the
+ * correctly rounded reciprocal and b's significand is not all ones; for the operands the camera-ray set-up feeds it
+ * (b an integer in [1, 65536]; a an integer in [0, 65536] or m 2^-24 with |m| <= 2^23) tools/exact_unary_check.hip tries every
+ * pair.  Three binary64 instructions instead of the eleven of the general division. */
+static inline TRT_HD double trt_div_by(double a, double b, double rb)
+{
+#if TRT_EXACT_DEVICE
+    const double q0 = a * rb;
+    const double r = __builtin_fma(-q0, b, a);
+    return __builtin_fma(r, rb, q0);
+#else
+    (void)rb;
+    return a / b;
+#endif
 }
 
 #endif /* TRT_EXACT_H */

@@ -120,6 +120,8 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
     td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
     td.fixed_pixels = (p->flags & TRT_FLAG_FIXED_PIXELS) ? 1u : 0u;
     td.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) ? 1u : 0u;
+    td.grid_ok = 0u;  // the host form of cameraRay divides
+    for (double& g : td.grid_rcp) g = 0.0;
     uint64_t r_cam = 0, r_sh = 0, r_ind = 0;
     const uint32_t S = (uint32_t)p->spp;  // one chunk: path id = s * npix + pixel
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : r_cam, r_sh, r_ind)

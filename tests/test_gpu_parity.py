@@ -661,8 +661,9 @@ def test_ray_offset_flag_matches_oracle(name, w, h, spp, renderer_factory):
 @pytest.mark.gpu
 def test_exact_sqrt_sequences_equal_ieee_on_every_input():
     """include/trt_exact.h: the short v_rsq-based sequences the kernels use for sqrtf(x) and 1.0f / sqrtf(x) return the bits of
-    hipcc's correctly rounded expansions for ALL 2^32 binary32 inputs (a unary function: the check is exhaustive, i.e. a proof).
-    The tool also checks that it really visited 2^32 inputs."""
+    hipcc's correctly rounded expansions for ALL 2^32 binary32 inputs (a unary function: the check is exhaustive, i.e. a proof),
+    and the three-instruction binary64 division of the pixel grid returns the bits of a / b for all 1.1e12 operand pairs the grid
+    can form.  The tool also checks that it really visited every input."""
     import subprocess
     exe = os.path.join(T.REPO_ROOT, "tools", "exact_unary_check")
     assert os.path.exists(exe), "tools/exact_unary_check is not built (make exactcheck)"
@@ -670,3 +671,6 @@ def test_exact_sqrt_sequences_equal_ieee_on_every_input():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if "inputs differ" in l]
     assert len(lines) == 4 and all(" 0 of 4294967296 inputs differ" in l for l in lines), r.stdout
+    # trt_div_by (the pixel grid's binary64 divisions by W - 1, H - 1, W, H): every operand pair the grid can form
+    div = [l for l in r.stdout.splitlines() if "operand pairs differ" in l]
+    assert len(div) == 1 and " 0 of 1103806660608 operand pairs differ" in div[0], r.stdout

@@ -504,12 +504,20 @@ struct Stream {
 // ------------------------------------- primary ray (main.cpp:88-95, a1/a2) ----
 // `fixed` (TRT_FLAG_FIXED_PIXELS): pixel (i, j) covers [j/W, (j+1)/W) x [(H-1-i)/H, (H-i)/H) of the image plane and the
 // jitter is uniform inside it, instead of Q1 (rows shifted by one, pitch 1/(H-1)) and Q2 (jitter of 1/W on a 1/(W-1) grid).
-TRT_HD inline void cameraRay(const trt_camera& cam, int W, int H, int i, int j, float u1, float u2, f3& o, f3& d, bool fixed = false)
+// `grid` (kernels only): the correctly rounded reciprocals 1 / (W - 1), 1 / (H - 1), 1 / W, 1 / H, formed once per render on the
+// host; with them the four binary64 divisions of the pixel grid are three instructions each (trt_div_by: the same bits, checked
+// for every operand pair the grid can produce).  Null: plain divisions (images beyond 65536 pixels a side, W or H of 1, hosts).
+TRT_HD inline void cameraRay(const trt_camera& cam, int W, int H, int i, int j, float u1, float u2, f3& o, f3& d, bool fixed = false, const double* grid = nullptr)
 {
     double x, y;
     if (fixed) {
         x = (double(j) + (double)u1) / double(W);
         y = (double(H - 1 - i) + (double)u2) / double(H);
+    } else if (grid) {
+        x = trt_div_by(double(j), double(W - 1.0), grid[0]);
+        y = trt_div_by(double(H - i), double(H - 1.0), grid[1]);  // Q1
+        x += trt_div_by((double)u1 - 0.5, double(W), grid[2]);      // Q2
+        y += trt_div_by((double)u2 - 0.5, double(H), grid[3]);
     } else {
         x = double(j) / double(W - 1.0);
         y = double(H - i) / double(H - 1.0);  // Q1
@@ -737,6 +745,8 @@ struct TileDesc {
     uint32_t ray_offset;    // TRT_FLAG_RAY_OFFSET
     uint32_t npix;        // rows * tile_w
     uint32_t seed, spp;
+    uint32_t grid_ok;     // grid_rcp may be used: 2 <= width, height <= 65536 (the operand range trt_div_by is checked for)
+    double grid_rcp[4];   // 1 / (W - 1), 1 / (H - 1), 1 / W, 1 / H, correctly rounded (host)
 };
 
 // Image row of packed row r of the tile: the table in global memory.  k_shade passes a look-up of its own (an LDS copy of
@@ -769,7 +779,7 @@ TRT_HD inline void primaryRay(const SceneDev& sc, const TileDesc& td, uint32_t s
     rng.ctr = 0;
     const float u1 = rng.next(), u2 = rng.next();  // jitter x, then y (main.cpp:92-93)
     f3 o, d;
-    cameraRay(sc.cam, td.width, td.height, y, x, u1, u2, o, d, td.fixed_pixels != 0u);
+    cameraRay(sc.cam, td.width, td.height, y, x, u1, u2, o, d, td.fixed_pixels != 0u, td.grid_ok ? td.grid_rcp : nullptr);
     ra = mk4(o.x, o.y, o.z, d.x);
     rb = mk4(d.y, d.z, u2f(pid), u2f(packMeta(rng.ctr, TRT_META_CAMERA, 0)));
 }

@@ -2,6 +2,7 @@
 // include/trt_exact.h return the bits of the IEEE-754 correctly rounded operations they stand for on gfx950:
 //   trt_sqrt(x)            == sqrtf(x)
 //   trt_sqrt_rsqrt2(x)     == (sqrtf(x), 1.0f / sqrtf(x))        (two roundings, as glm::normalize does it)
+//   trt_div_by(a, b, 1/b)  == a / b in binary64, for every (a, b) the pixel grid of cameraRay() can form (1.1e12 pairs)
 // The reference side is what hipcc emits for the plain expressions (correctly rounded division and square root, the HIP
 // default).  A unary fp32 function has 2^32 inputs: the check is a proof, not a sample.
 // build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Iinclude -o tools/exact_unary_check tools/exact_unary_check.hip
@@ -46,6 +47,28 @@ __global__ __launch_bounds__(256) void k_check(int which, int raw, unsigned long
     atomicAdd(n_bad + 1, seen);
 }
 
+
+// trt_div_by(a, b, 1 / b) == a / b in binary64 for every operand pair the pixel grid of cameraRay() can form:
+// b = blockIdx.x + 1 in [1, 65536]; a = an integer in [0, 65536] (pixel column / row counts) or m 2^-24, m in [-2^23, 2^23)
+// ((u - 0.5) for a 24-bit uniform u).  1.1e12 pairs.
+__global__ __launch_bounds__(256) void k_check_div(unsigned long long* n_bad, unsigned long long* n_seen, unsigned long long* first_bad)
+{
+    const double b = (double)(blockIdx.x + 1u);
+    const double rb = 1.0 / b;
+    unsigned long long bad = 0, seen = 0;
+    for (uint32_t k = threadIdx.x; k < 65537u + (1u << 24); k += 256u) {
+        const double a = k <= 65536u ? (double)k : ((double)(int)(k - 65537u) - 8388608.0) * 5.9604644775390625e-8;
+        const double ref = a / b, got = trt_div_by(a, b, rb);
+        seen++;
+        if (__double_as_longlong(ref) != __double_as_longlong(got)) {
+            bad++;
+            atomicMin(first_bad, ((unsigned long long)(blockIdx.x + 1u) << 32) | k);
+        }
+    }
+    if (bad) atomicAdd(n_bad, bad);
+    atomicAdd(n_seen, seen);
+}
+
 int main(int argc, char** argv)
 {
     const int raw = argc > 1 && std::atoi(argv[1]) != 0;
@@ -79,6 +102,21 @@ int main(int argc, char** argv)
         }
         std::printf("\n");
         if (bad && !raw) rc = 1;
+    }
+    {
+        unsigned long long* d3;
+        CK(hipMalloc(&d3, 24));
+        CK(hipMemset(d3, 0, 16));
+        CK(hipMemset(d3 + 2, 0xFF, 8));
+        hipLaunchKernelGGL(k_check_div, dim3(65536), dim3(256), 0, 0, d3, d3 + 1, d3 + 2);
+        CK(hipDeviceSynchronize());
+        unsigned long long h3[3];
+        CK(hipMemcpy(h3, d3, 24, hipMemcpyDeviceToHost));
+        const unsigned long long want = 65536ull * (65537ull + (1ull << 24));
+        if (h3[1] != want) { std::printf("internal error: %llu operand pairs visited, not %llu\n", h3[1], want); return 2; }
+        std::printf("%-32s (as shipped): %llu of %llu operand pairs differ", "trt_div_by == a / b (binary64)", h3[0], want);
+        if (h3[0]) { std::printf("; first b=%llu k=%llu", h3[2] >> 32, h3[2] & 0xFFFFFFFFull); rc = 1; }
+        std::printf("\n");
     }
     return rc;
 }
