@@ -120,6 +120,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
     td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
     td.fixed_pixels = (p->flags & TRT_FLAG_FIXED_PIXELS) ? 1u : 0u;
     td.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) ? 1u : 0u;
+    td.npix_magic = magicOf(npix); td.tile_w_magic = magicOf(tw);
     td.grid_ok = 0u;  // the host form of cameraRay divides
     for (double& g : td.grid_rcp) g = 0.0;
     uint64_t r_cam = 0, r_sh = 0, r_ind = 0;
@@ -202,4 +203,13 @@ extern "C" int hostsim_trace(const trt_scene* s, uint64_t n, const float* org, c
     }
     if (counts) { counts[0] = ci; counts[1] = ct; }
     return 0;
+}
+
+// divMagic(n, d, magicOf(d)) against n / d for a list of numerators: returns the number of mismatches (tests/test_hostsim_parity.py)
+extern "C" uint64_t hostsim_div_magic_mismatches(uint32_t d, const uint32_t* n, uint64_t count)
+{
+    const uint32_t m = magicOf(d);
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < count; ++i) bad += divMagic(n[i], d, m) != n[i] / d ? 1u : 0u;
+    return bad;
 }

@@ -199,3 +199,22 @@ def test_ray_offset_removes_the_self_hits_of_q6():
     assert not np.array_equal(a, b)
     assert abs(float(b.mean()) / float(a.mean()) - 1.0) < 0.05
     assert sb.shaded_hits < sa.shaded_hits  # fewer vertices: the immediate re-hits are gone
+
+
+def test_magic_number_division_is_exact():
+    """divMagic() (trt_path.h: path id -> sample, row, column with host-formed magic numbers) equals the integer division
+    for divisors of every size, on the edges of the 32-bit range and on a few million random numerators each."""
+    import ctypes as C
+    lib = H.lib()
+    lib.hostsim_div_magic_mismatches.restype = C.c_uint64
+    lib.hostsim_div_magic_mismatches.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64]
+    rng = np.random.default_rng(7)
+    divisors = [1, 2, 3, 5, 7, 64, 1000, 1080, 1920, 65535, 65536, 65537, 1920 * 1080, 3840 * 2160, 2**31 - 1, 2**31, 2**32 - 1]
+    divisors += [int(x) for x in rng.integers(1, 2**32, 40, dtype=np.uint64)]
+    for d in divisors:
+        n = rng.integers(0, 2**32, 2_000_000, dtype=np.uint64).astype(np.uint32)
+        edges = np.array([0, 1, d - 1, d, (d + 1) & 0xFFFFFFFF, 2**32 - 1, 2**32 - 2, 2**31, (2**32 // d) * d - 1 & 0xFFFFFFFF, ((2**32 // d) * d) & 0xFFFFFFFF], dtype=np.uint64).astype(np.uint32)
+        mult = (np.arange(1, 200001, dtype=np.uint64) * d)  # multiples of d and their predecessors: where a quotient steps
+        mult = mult[mult < 2**32]
+        n = np.ascontiguousarray(np.concatenate([n, edges, mult.astype(np.uint32), (mult - 1).astype(np.uint32)]))
+        assert lib.hostsim_div_magic_mismatches(d, n.ctypes.data, n.size) == 0, d

@@ -745,9 +745,21 @@ struct TileDesc {
     uint32_t ray_offset;    // TRT_FLAG_RAY_OFFSET
     uint32_t npix;        // rows * tile_w
     uint32_t seed, spp;
+    uint32_t npix_magic, tile_w_magic;  // magicOf(npix), magicOf(tile_w)
     uint32_t grid_ok;     // grid_rcp may be used: 2 <= width, height <= 65536 (the operand range trt_div_by is checked for)
     double grid_rcp[4];   // 1 / (W - 1), 1 / (H - 1), 1 / W, 1 / H, correctly rounded (host)
 };
+
+// n / d for a divisor whose magic number m = min(floor(2^32 / d), 2^32 - 1) was formed on the host (TileDesc): the high word of
+// n m is floor(n / d) or one less for every n < 2^32 (n m / 2^32 > n / d - n / 2^32 > n / d - 1), so one correction gives the
+// quotient: two multiplications instead of the twenty-instruction general division (two of them per path vertex: the RNG key).
+TRT_HD inline uint32_t divMagic(uint32_t n, uint32_t d, uint32_t m)
+{
+    uint32_t q = (uint32_t)(((uint64_t)n * m) >> 32);
+    if (n - q * d >= d) q++;
+    return q;
+}
+TRT_HD inline uint32_t magicOf(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / d); }
 
 // Image row of packed row r of the tile: the table in global memory.  k_shade passes a look-up of its own (an LDS copy of
 // the table: a dependent global load per vertex otherwise).
@@ -759,8 +771,8 @@ struct RowsGlobal {
 template <class Rows = RowsGlobal>
 TRT_HD inline trt_rng_key pathKey(const TileDesc& td, uint32_t s0, uint32_t pid, Rows rows = Rows())
 {
-    const uint32_t s_local = pid / td.npix, pl = pid - s_local * td.npix;
-    const uint32_t r = pl / (uint32_t)td.tile_w, c = pl - r * (uint32_t)td.tile_w;
+    const uint32_t s_local = divMagic(pid, td.npix, td.npix_magic), pl = pid - s_local * td.npix;
+    const uint32_t r = divMagic(pl, (uint32_t)td.tile_w, td.tile_w_magic), c = pl - r * (uint32_t)td.tile_w;
     const uint32_t pixel = (uint32_t)rows(td, r) * (uint32_t)td.width + (uint32_t)(td.x0 + (int)c);
     return trt_rng_make_key(td.seed, pixel, s0 + s_local);
 }
@@ -771,8 +783,8 @@ TRT_HD inline trt_rng_key pathKey(const TileDesc& td, uint32_t s0, uint32_t pid,
 template <class Rows = RowsGlobal>
 TRT_HD inline void primaryRay(const SceneDev& sc, const TileDesc& td, uint32_t s0, uint32_t pid, f4& ra, f4& rb, Rows rows = Rows())
 {
-    const uint32_t s_local = pid / td.npix, pl = pid - s_local * td.npix;
-    const uint32_t r = pl / (uint32_t)td.tile_w, c = pl - r * (uint32_t)td.tile_w;
+    const uint32_t s_local = divMagic(pid, td.npix, td.npix_magic), pl = pid - s_local * td.npix;
+    const uint32_t r = divMagic(pl, (uint32_t)td.tile_w, td.tile_w_magic), c = pl - r * (uint32_t)td.tile_w;
     const int y = rows(td, r), x = td.x0 + (int)c;
     Stream rng;
     rng.key = trt_rng_make_key(td.seed, (uint32_t)y * (uint32_t)td.width + (uint32_t)x, s0 + s_local);
