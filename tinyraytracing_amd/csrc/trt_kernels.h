@@ -110,6 +110,10 @@ __device__ inline uint32_t xcdSwizzle(uint32_t bid, uint32_t nblocks)
     return (nblocks & 7u) ? bid : (bid & 7u) * (nblocks >> 3) + (bid >> 3);
 }
 
+// __ballot() takes an int: the predicate is widened to 0 / 1 (v_cndmask) and compared again (v_cmp_ne), two VALU instructions
+// per vote that the compiler does not always fold away; the builtin takes the lane mask as it is.
+__device__ __forceinline__ unsigned long long ballotb(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ inline unsigned long long waveSum(unsigned long long v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -217,7 +221,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
     uint32_t n_pend = 0;
     // division + cut + fold of every parked candidate, slot by slot (= in the order they were found)
     auto flush = [&]() {
-        for (uint32_t s = 0; __ballot(s < n_pend) != 0ull; ++s) {
+        for (uint32_t s = 0; ballotb(s < n_pend) != 0ull; ++s) {
             if (s < n_pend) {
                 const f4 e = my_pend[s * STRIDE];
                 const float t = e.x / e.y;
@@ -240,7 +244,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
     };
     for (uint32_t ni = 0; ni < n_nodes; ++ni) {
         const bool at = (reach >> ni) & 1u;
-        if (__ballot(at) == 0ull) continue;
+        if (ballotb(at) == 0ull) continue;
         const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + ni);  // wave-uniform address
         const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
         if (COUNT && at) n_inner++;
@@ -256,14 +260,18 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
                 reach |= hc[c] ? (1u << ref) : 0u;
                 continue;
             }
-            if (__ballot(hc[c]) == 0ull) continue;
+            const unsigned long long m_hc = ballotb(hc[c]);
+            if (m_hc == 0ull) continue;
             const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
             for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
                 const TriIsect T = sc.tri_isect[first + k];  // wave-uniform address
                 if (COUNT && hc[c]) n_tri++;
                 float tn, un, vn, det;
-                const bool cand = triCandidate(T, o, d, tn, un, vn, det) && hc[c];
-                if (__ballot(cand && n_pend == (uint32_t)TRT_PEND_SLOTS) != 0ull) flush();  // a full queue: empty all of them first
+                bool ok_det, ok_in;
+                triCandidateParts(T, o, d, tn, un, vn, det, ok_det, ok_in);
+                const bool cand = ok_det && ok_in && hc[c];
+                // a full queue among the candidates: empty all of them first (votes on the single compares: their own lane masks)
+                if ((ballotb(ok_det) & ballotb(ok_in) & m_hc & ballotb(n_pend == (uint32_t)TRT_PEND_SLOTS)) != 0ull) flush();
                 if (cand) {
                     my_pend[n_pend * STRIDE] = mk4(tn, det, u2f(first + k), u2f(ref));
                     n_pend++;

@@ -232,7 +232,9 @@ TRT_HD inline TriIsect makeTriIsect(const float* v9, int32_t mat, bool emissive)
 // u = un/det, v = vn/det are left to the caller (needed once per ray).
 // triCandidate: everything up to the acceptance test; tn, un, vn, det are the numerators / the denominator
 // (det > 0) of t, u, v.  triTest = triCandidate + the division + the t < 0.0005 cut.
-TRT_HD inline bool triCandidate(const TriIsect& T, f3 o, f3 d, float& tn_out, float& un_out, float& vn_out, float& det_out)
+// The two halves of the acceptance test are returned separately (ok_det: not parallel; ok_in: strictly inside): a wave vote on
+// each is the compare's own lane mask, a vote on their conjunction is two more VALU instructions (trt_kernels.h, ballotb()).
+TRT_HD inline void triCandidateParts(const TriIsect& T, f3 o, f3 d, float& tn_out, float& un_out, float& vn_out, float& det_out, bool& ok_det, bool& ok_in)
 {
     const float v0x = T.a.x, v0y = T.a.y, v0z = T.a.z;
     const float e1x = T.a.w, e1y = T.b.x, e1z = T.b.y;
@@ -260,7 +262,14 @@ TRT_HD inline bool triCandidate(const TriIsect& T, f3 o, f3 d, float& tn_out, fl
     un_out = un;
     vn_out = vn;
     det_out = det;
-    return !(det < T.c.y) && bmax < 0x7F800000u;
+    ok_det = !(det < T.c.y);
+    ok_in = bmax < 0x7F800000u;
+}
+TRT_HD inline bool triCandidate(const TriIsect& T, f3 o, f3 d, float& tn_out, float& un_out, float& vn_out, float& det_out)
+{
+    bool ok_det, ok_in;
+    triCandidateParts(T, o, d, tn_out, un_out, vn_out, det_out, ok_det, ok_in);
+    return ok_det && ok_in;
 }
 TRT_HD inline bool triTest(const TriIsect& T, f3 o, f3 d, float& t_out, float& un_out, float& vn_out, float& det_out)
 {
