@@ -37,6 +37,10 @@ namespace trtd {
 #define TRT_TRACE_BOUNDS __launch_bounds__(256)
 #endif
 constexpr int TRT_TRACE_BLOCK = 256;
+// TRT_SHADOW_UNORDERED: the persistent drivers take the hit children of a node in slot order for shadow rays (no sort)
+#ifndef TRT_SHADOW_UNORDERED
+#define TRT_SHADOW_UNORDERED 0
+#endif
 #ifndef TRT_LDS_STACK_MAX_LEVELS
 #define TRT_LDS_STACK_MAX_LEVELS 16
 #endif
@@ -425,7 +429,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             if (m == 0ull) break;
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
-                if (!innerStep<NK>(sc, cur, sp, stk, o, inv, best_t)) {
+                if (!innerStep<NK, LdsStack<DEPTH, SPILL>, !(SHADOW && TRT_SHADOW_UNORDERED)>(sc, cur, sp, stk, o, inv, best_t)) {
                     if (sp != 0) cur = stk.pop(--sp);
                     else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }  // nothing in front of the hint: search again without it
                     else cur = TRT_REF_DONE;
@@ -483,7 +487,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         if (sc.sched_in_w * (uint32_t)__popcll(m_in) >= sc.sched_lf_w * (uint32_t)__popcll(m_blk)) {
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
-                if (!innerStep<NK>(sc, cur, sp, stk, o, inv, best_t)) adv = true;
+                if (!innerStep<NK, LdsStack<DEPTH, SPILL>, !(SHADOW && TRT_SHADOW_UNORDERED)>(sc, cur, sp, stk, o, inv, best_t)) adv = true;
             }
         } else {
             if (leaf_work) {
@@ -537,7 +541,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             // ---- inner-node step
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
-                if (innerStep<NK>(sc, cur, sp, stk, o, inv, best_t)) { lk = 0; lt = TRT_INF; li = -1; }
+                if (innerStep<NK, LdsStack<DEPTH, SPILL>, !(SHADOW && TRT_SHADOW_UNORDERED)>(sc, cur, sp, stk, o, inv, best_t)) { lk = 0; lt = TRT_INF; li = -1; }
                 else adv = true;
             }
         } else {

@@ -324,7 +324,10 @@ TRT_HD inline bool leafBoxPasses(const SceneDev& sc, uint32_t first, f3 o, f3 in
     return boxTest(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, e);
 }
 
-template <int NK, class Stack>
+// ORDERED = false: the children that are hit are taken in slot order (the first one next, the others pushed) instead of
+// nearest first.  The hit does not depend on the order (see traceClosest); for a shadow ray that nothing occludes neither does
+// the number of nodes visited — its search is bounded by the distance to the light from the start — so the sort buys nothing there.
+template <int NK, class Stack, bool ORDERED = true>
 TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& stk, f3 o, f3 inv, float best_t)
 {
     float e0, e1, e2, e3;
@@ -399,6 +402,16 @@ TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& 
 #undef TRT_B3
     h0 = h0 && (sw & (1u << 24)); h1 = h1 && (sw & (1u << 25)); h2 = h2 && (sw & (1u << 26)); h3 = h3 && (sw & (1u << 27));
     r0 = f2u(rf.x); r1 = f2u(rf.y); r2 = f2u(rf.z); r3 = f2u(rf.w);
+    }
+    if (!ORDERED) {
+        if (!(h0 || h1 || h2 || h3)) return false;
+        // slot order: push the later ones first, so that the earliest hit child is next and the others follow in slot order
+        const bool b3 = h3 && (h0 || h1 || h2), b2 = h2 && (h0 || h1), b1 = h1 && h0;
+        if (b3) stk.push(sp++, r3);
+        if (b2) stk.push(sp++, r2);
+        if (b1) stk.push(sp++, r1);
+        cur = h0 ? r0 : (h1 ? r1 : (h2 ? r2 : r3));
+        return true;
     }
     const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     if (n == 0) return false;
