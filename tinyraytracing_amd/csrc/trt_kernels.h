@@ -390,8 +390,8 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
     for (;;) {
         // ---- write back finished rays and refill free lanes from the wave's slice, in batches
         const bool working = cur < TRT_REF_DONE;
-        const unsigned long long m_work = __ballot(working);
-        const unsigned long long m_done = __ballot(cur == TRT_REF_DONE);
+        const unsigned long long m_work = ballotb(working);
+        const unsigned long long m_done = ballotb(cur == TRT_REF_DONE);
         const unsigned long long m_free = ~m_work;  // finished or empty lanes
         const bool can_fill = next < end;
         if (m_work == 0ull || (m_done != 0ull && (uint32_t)__popcll(can_fill ? m_free : m_done) >= sc.refill_min)) {
@@ -418,14 +418,14 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                 const uint32_t taken = (uint32_t)__popcll(m_free);
                 next = (end - next) < taken ? end : next + taken;
             }
-            if (__ballot(cur < TRT_REF_DONE) == 0ull) break;  // nothing left in the slice
+            if (ballotb(cur < TRT_REF_DONE) == 0ull) break;  // nothing left in the slice
         }
 
         if constexpr (IMPL == 2) {
         // ---- inner-node phase: until no lane of the wave holds an inner node
         for (;;) {
             const bool is_inner = !(cur & TRT_LEAF_BIT);
-            const unsigned long long m = __ballot(is_inner);
+            const unsigned long long m = ballotb(is_inner);
             if (m == 0ull) break;
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
@@ -439,7 +439,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         // ---- leaf phase: every working lane now holds a leaf
         for (;;) {
             const bool is_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
-            const unsigned long long m = __ballot(is_leaf);
+            const unsigned long long m = ballotb(is_leaf);
             if (m == 0ull) break;
             if (is_leaf) {
                 const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
@@ -482,7 +482,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         const bool is_inner = !(cur & TRT_LEAF_BIT);
         const bool cur_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
         const bool leaf_work = cur_leaf || post != TRT_REF_IDLE;
-        const unsigned long long m_in = __ballot(is_inner), m_blk = __ballot(cur_leaf), m_lw = __ballot(leaf_work);
+        const unsigned long long m_in = ballotb(is_inner), m_blk = ballotb(cur_leaf), m_lw = ballotb(leaf_work);
         bool adv = false;
         if (sc.sched_in_w * (uint32_t)__popcll(m_in) >= sc.sched_lf_w * (uint32_t)__popcll(m_blk)) {
             if (is_inner) {
@@ -535,7 +535,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         } else {
         const bool is_inner = !(cur & TRT_LEAF_BIT);
         const bool is_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
-        const unsigned long long m_in = __ballot(is_inner), m_lf = __ballot(is_leaf);
+        const unsigned long long m_in = ballotb(is_inner), m_lf = ballotb(is_leaf);
         bool adv = false;  // this lane is done with its node: take the next one off the stack, or finish the ray
         if (sc.sched_in_w * (uint32_t)__popcll(m_in) >= sc.sched_lf_w * (uint32_t)__popcll(m_lf)) {
             // ---- inner-node step
@@ -660,7 +660,7 @@ __device__ inline uint32_t* blockStage(bool flag, uint32_t* counter, uint32_t* s
 {
     constexpr int NW = BLOCK / 64;
     uint32_t* s = s_cnt + parity * (NW + 1);
-    const unsigned long long ballot = __ballot(flag);
+    const unsigned long long ballot = ballotb(flag);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
     if (lane == 0) s[wave] = (uint32_t)__popcll(ballot);
@@ -684,7 +684,7 @@ __device__ inline void blockStage2(bool fa, bool fb, unsigned long long* counter
                                    const uint32_t* pend_s, uint32_t pend_base, unsigned long long& base)
 {
     constexpr int NW = BLOCK / 64;
-    const unsigned long long ba = __ballot(fa), bb = __ballot(fb);
+    const unsigned long long ba = ballotb(fa), bb = ballotb(fb);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
     rank_a = (uint32_t)__popcll(ba & below);
@@ -844,9 +844,9 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             }
             if (c.had_hit) bounce_depth = c.depth;
         }
-        const unsigned long long ok_ballot = __ballot(c.shade_ok);
+        const unsigned long long ok_ballot = ballotb(c.shade_ok);
         if ((threadIdx.x & 63u) == 0 && ok_ballot) atomicAdd(&s_shaded, (uint32_t)__popcll(ok_ballot));
-        if (__ballot(c.had_hit) && (threadIdx.x & 63u) == 0) s_anyhit = 1;
+        if (ballotb(c.had_hit) && (threadIdx.x & 63u) == 0) s_anyhit = 1;
 
         // Queue slots come from one atomicAdd per block and queue (blockStage), and that atomic's round trip
         // is taken off the critical path: the rays of a stage are written one stage later, after the NEXT
