@@ -159,7 +159,7 @@ inline bool triTest(const Tri& T, V3 o, V3 d, float& t_out, float& u_out, float&
 // ----------------------------------------------------- interactAABB (a4) ----
 // bvh.cpp:231-245.  inv = 1/d is formed in double there and narrowed; for a
 // binary32 d that equals the correctly rounded fp32 quotient.
-inline float aabb(const float* lo, const float* hi, V3 o, V3 inv)
+inline float aabb(const float* lo, const float* hi, V3 o, V3 inv, float* entry = nullptr)
 {
     const float inx = (hi[0] - o.x) * inv.x, iny = (hi[1] - o.y) * inv.y, inz = (hi[2] - o.z) * inv.z;
     const float outx = (lo[0] - o.x) * inv.x, outy = (lo[1] - o.y) * inv.y, outz = (lo[2] - o.z) * inv.z;
@@ -167,6 +167,7 @@ inline float aabb(const float* lo, const float* hi, V3 o, V3 inv)
     const float tminx = gmin(inx, outx), tminy = gmin(iny, outy), tminz = gmin(inz, outz);
     const float t1 = gmin(tmaxx, gmin(tmaxy, tmaxz));
     const float t0 = gmax(tminx, gmax(tminy, tminz));
+    if (entry) *entry = t0;
     return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
 }
 
@@ -177,13 +178,19 @@ struct Tracer {
 
     // interactBVHNode (bvh.cpp:211-229): scan in index order; replace when
     // strictly nearer, or equally near and emissive.
-    Hit leafScan(uint32_t first, uint32_t count, V3 o, V3 d) const
+    // `entry`: the entry distance of the leaf's own box.  A hit IN FRONT of the box of its leaf does not count: for a ray within
+    // ~1e-4 rad of a triangle's plane the Moller-Trumbore distance can come out well in front of the triangle while its
+    // barycentrics still say "inside"; the reference applies its inside test to the computed point P = o + d t
+    // (bvh.cpp:191-198) and never produces such a hit.  (It is also what makes the kernels' culled traversal return this
+    // unculled one's result for every input: an accepted t is never smaller than the entry of any box around its triangle.)
+    Hit leafScan(uint32_t first, uint32_t count, V3 o, V3 d, float entry = -TRT_INF) const
     {
         Hit res;
         for (uint32_t i = first; i < first + count; ++i) {
             float t, u, v;
             if (cnt) cnt->tests[kind]++;
             if (!triTest(sv.tris[i], o, d, t, u, v)) continue;
+            if (t < entry) continue;
             if ((t == res.t && sv.emissive((int32_t)i)) || t < res.t) {
                 res.t = t;
                 res.tri = (int32_t)i;
@@ -195,39 +202,41 @@ struct Tracer {
     }
 
     // traverseBVH (bvh.cpp:146-175)
-    Hit traverse(uint32_t ref, V3 o, V3 d, V3 inv) const
+    Hit traverse(uint32_t ref, V3 o, V3 d, V3 inv, float entry = -TRT_INF) const
     {
-        if (ref & TRT_LEAF_BIT) return leafScan(TRT_LEAF_FIRST(ref), TRT_LEAF_COUNT(ref), o, d);
+        if (ref & TRT_LEAF_BIT) return leafScan(TRT_LEAF_FIRST(ref), TRT_LEAF_COUNT(ref), o, d, entry);
         const trt_bvh_node& n = sv.s->nodes[ref];
         if (cnt) cnt->inner[kind]++;
-        const float d1 = aabb(n.lo0, n.hi0, o, inv);
-        const float d2 = aabb(n.lo1, n.hi1, o, inv);
+        float e1, e2;
+        const float d1 = aabb(n.lo0, n.hi0, o, inv, &e1);
+        const float d2 = aabb(n.lo1, n.hi1, o, inv, &e2);
         Hit r1, r2;
-        if (d1 > 0) r1 = traverse(n.child0, o, d, inv);
-        if (d2 > 0) r2 = traverse(n.child1, o, d, inv);
+        if (d1 > 0) r1 = traverse(n.child0, o, d, inv, e1);
+        if (d2 > 0) r2 = traverse(n.child1, o, d, inv, e2);
         if (r1.t == r2.t) return (r1.tri >= 0 && sv.emissive(r1.tri)) ? r1 : r2;  // bvh.cpp:168-172
         return r1.t < r2.t ? r1 : r2;
     }
 
     // Occlusion test of TRT_FLAG_FIXED_NEE: does anything lie in front of t_max?  Same visit set as traverse().
-    bool anyBefore(uint32_t ref, V3 o, V3 d, V3 inv, float t_max) const
+    bool anyBefore(uint32_t ref, V3 o, V3 d, V3 inv, float t_max, float entry = -TRT_INF) const
     {
         if (ref & TRT_LEAF_BIT) {
             bool found = false;
             for (uint32_t i = TRT_LEAF_FIRST(ref); i < TRT_LEAF_FIRST(ref) + TRT_LEAF_COUNT(ref); ++i) {
                 float t, u, v;
                 if (cnt) cnt->tests[kind]++;
-                if (triTest(sv.tris[i], o, d, t, u, v) && t < t_max) found = true;
+                if (triTest(sv.tris[i], o, d, t, u, v) && !(t < entry) && t < t_max) found = true;  // leafScan's rule
             }
             return found;
         }
         const trt_bvh_node& n = sv.s->nodes[ref];
         if (cnt) cnt->inner[kind]++;
-        const float d1 = aabb(n.lo0, n.hi0, o, inv);
-        const float d2 = aabb(n.lo1, n.hi1, o, inv);
+        float e1, e2;
+        const float d1 = aabb(n.lo0, n.hi0, o, inv, &e1);
+        const float d2 = aabb(n.lo1, n.hi1, o, inv, &e2);
         bool found = false;
-        if (d1 > 0) found = anyBefore(n.child0, o, d, inv, t_max);
-        if (d2 > 0) found = anyBefore(n.child1, o, d, inv, t_max) || found;
+        if (d1 > 0) found = anyBefore(n.child0, o, d, inv, t_max, e1);
+        if (d2 > 0) found = anyBefore(n.child1, o, d, inv, t_max, e2) || found;
         return found;
     }
     bool occluded(V3 o, V3 d, float t_max) const

@@ -31,6 +31,7 @@ struct HostScene {
     std::vector<LightTriDev> ltris;
     WideTree wide;
     CompressedTree comp;
+    std::vector<f4> leaf_boxes;
     int nk = 0;  // node kind the traversal walks: 0 exact wide nodes (trt_create's default), 1 compressed (TRT_NODE_KIND=1)
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
@@ -64,7 +65,8 @@ struct HostScene {
         sc.n_wnodes = (uint32_t)wide.nodes.size();
         comp = compressWide(wide, s->nodes, s->n_nodes, s->n_tris);
         sc.cnodes = comp.ok ? comp.nodes.data() : nullptr;
-        sc.leaf_box = comp.ok ? comp.leaf_box.data() : nullptr;
+        leaf_boxes = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris);
+        sc.leaf_box = leaf_boxes.data();
         nk = (comp.ok && g_node_kind != 0) ? 1 : 0;
         sc.tri_isect = isect.data();
         sc.tri_shade = shade.data();

@@ -149,7 +149,7 @@ def test_sample_chunking_is_invisible(renderer_factory):
     s = get_scene("back", 96, 96)
     r = renderer_factory(s)
     big, st_big = r.render(T.make_params(96, 96, 24, 3))
-    per_path = 2 * 48 + 16 + 16 + 48
+    per_path = 2 * 48 + 16 + 16 + 48 + 4  # two ray queues, hit, Lacc, one shadow queue, redo list
     small, st_small = r.render(T.make_params(96, 96, 24, 3, mem_budget=96 * 96 * 5 * per_path))
     assert st_big.passes == 1 and st_small.passes == 5
     assert np.array_equal(big, small)
@@ -674,3 +674,20 @@ def test_exact_sqrt_sequences_equal_ieee_on_every_input():
     # trt_div_by (the pixel grid's binary64 divisions by W - 1, H - 1, W, H): every operand pair the grid can form
     div = [l for l in r.stdout.splitlines() if "operand pairs differ" in l]
     assert len(div) == 1 and " 0 of 1103806660608 operand pairs differ" in div[0], r.stdout
+
+
+def test_hit_in_front_of_its_leaf_box_does_not_count_on_the_gpu(monkeypatch):
+    """The configuration tools/fuzz_parity.py found (see tests/test_hostsim_parity.py): a grazing hit in front of the box of its own
+    leaf.  Every wave driver must agree with the oracle, in the occlusion-test mode (where it was found) and in parity mode."""
+    sc = get_scene("veach-mis", 320, 180)
+    for flags in (T.TRT_FLAG_FIXED_NEE, 0):
+        p = T.make_params(320, 180, 33, 2073828938, tile=(132, 93, 156, 104), rows=(1, 3, 1), flags=flags)
+        ref, ost = O.render(sc.flat, p)
+        for impl in ("", "1", "2", "3", "4"):
+            if impl:
+                monkeypatch.setenv("TRT_TRACE_IMPL", impl)
+            else:
+                monkeypatch.delenv("TRT_TRACE_IMPL", raising=False)
+            img, st = T.Renderer(sc, 0).render(p)
+            assert_same_image(img, ref, f"flags {flags} impl {impl or 'default'}")
+            assert (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)

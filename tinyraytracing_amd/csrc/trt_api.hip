@@ -243,9 +243,9 @@ uint32_t tailGrid(uint32_t n)
 // depth fits, else 16 levels + a global spill area (16 KiB per block keeps 8 waves per SIMD resident);
 // the wave driver (trt_kernels.h) is the static one for shallow trees, the scheduler one otherwise.
 template <bool COUNT, bool PRIMARY>
-void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats);
+void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats, RedoList redo);
 template <bool COUNT>
-void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any);
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any, RedoList redo);
 
 struct Timer {
     trt_handle* h;
@@ -284,9 +284,9 @@ struct Timer {
 
 // One kernel per (driver, LDS depth, node kind); the scene picks the combination once, in trt_create.
 #define TRT_LAUNCH_CLOSEST(DEPTH, SPILL, IMPL, NK) \
-    hipLaunchKernelGGL((k_trace_closest<COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats)
+    hipLaunchKernelGGL((k_trace_closest<COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats, redo)
 #define TRT_LAUNCH_SHADOW(DEPTH, SPILL, IMPL, NK) \
-    hipLaunchKernelGGL((k_trace_shadow<COUNT, DEPTH, SPILL, IMPL, NK>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any)
+    hipLaunchKernelGGL((k_trace_shadow<COUNT, DEPTH, SPILL, IMPL, NK>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any, redo)
 #define TRT_BY_DEPTH(LAUNCH, IMPL, NK)                                       \
     do {                                                                     \
         if (h->depth <= 8) LAUNCH(8, false, IMPL, NK);                       \
@@ -301,22 +301,32 @@ struct Timer {
         else TRT_BY_DEPTH(LAUNCH, 3, NK);                                    \
     } while (0)
 
+// Behind every traversal launch of a per-lane driver: k_trace_fix (one block) traces the rays of the launch's redo list again in the
+// exact form (trt_kernels.h, RedoList).  The wave-uniform walk applies the rule on the spot and has no list.
 template <bool COUNT, bool PRIMARY>
-void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats)
+void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats, RedoList redo)
 {
     const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->trace_impl == 0) TRT_LAUNCH_CLOSEST(1, false, 0, 0);
-    else if (h->node_kind == 1) TRT_BY_IMPL(TRT_LAUNCH_CLOSEST, 1);
+    if (h->trace_impl == 0) { TRT_LAUNCH_CLOSEST(1, false, 0, 0); return; }
+    if (h->node_kind == 1) TRT_BY_IMPL(TRT_LAUNCH_CLOSEST, 1);
     else TRT_BY_IMPL(TRT_LAUNCH_CLOSEST, 0);
+    if (h->node_kind == 1) hipLaunchKernelGGL((k_trace_fix<false, PRIMARY, 1>), dim3(1), b, 0, stream, h->sc, src, hit, (const f4*)nullptr, 0u, (f4*)nullptr, spill, SPILL_STRIDE, redo, 0u);
+    else hipLaunchKernelGGL((k_trace_fix<false, PRIMARY, 0>), dim3(1), b, 0, stream, h->sc, src, hit, (const f4*)nullptr, 0u, (f4*)nullptr, spill, SPILL_STRIDE, redo, 0u);
 }
 
 template <bool COUNT>
-void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any)
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any, RedoList redo)
 {
     const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
-    if (h->trace_impl == 0) TRT_LAUNCH_SHADOW(1, false, 0, 0);
-    else if (h->node_kind == 1) TRT_BY_IMPL(TRT_LAUNCH_SHADOW, 1);
+    if (h->trace_impl == 0) { TRT_LAUNCH_SHADOW(1, false, 0, 0); return; }
+    if (h->node_kind == 1) TRT_BY_IMPL(TRT_LAUNCH_SHADOW, 1);
     else TRT_BY_IMPL(TRT_LAUNCH_SHADOW, 0);
+    RaySource src;
+    src.ra = sq.sa;
+    src.rb = sq.sb;
+    src.s0 = 0;
+    if (h->node_kind == 1) hipLaunchKernelGGL((k_trace_fix<true, false, 1>), dim3(1), b, 0, stream, h->sc, src, (f4*)nullptr, (const f4*)sq.sw, light_mat, Lacc, spill, SPILL_STRIDE, redo, any);
+    else hipLaunchKernelGGL((k_trace_fix<true, false, 0>), dim3(1), b, 0, stream, h->sc, src, (f4*)nullptr, (const f4*)sq.sw, light_mat, Lacc, spill, SPILL_STRIDE, redo, any);
 }
 
 }  // namespace
@@ -428,10 +438,13 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         h->sc.wnodes = nullptr;
         h->sc.cnodes = nullptr;
         h->sc.leaf_box = nullptr;
+        {   // the caller's box of every leaf: a hit in front of its own leaf's box does not count (leafEntry(), trt_path.h)
+            const std::vector<f4> lb = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris);
+            if (int e = upload(h.get(), lb.data(), lb.size(), &h->sc.leaf_box)) return e;
+        }
         if (comp.ok) {
             h->node_kind = 1;
             if (int e = upload(h.get(), comp.nodes.data(), comp.nodes.size(), &h->sc.cnodes)) return e;
-            if (int e = upload(h.get(), comp.leaf_box.data(), comp.leaf_box.size(), &h->sc.leaf_box)) return e;
         } else {
             if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
         }
@@ -559,6 +572,7 @@ struct PassSlot {
     uint32_t* host_counts = nullptr;  // pinned, device-visible: 2 * COUNT_ROW counters + the sequence word
     uint32_t seq = 0;                 // last sequence number asked for
     uint32_t* spill = nullptr;
+    RedoList redo{nullptr, nullptr};  // rays the traversal kernels hand to k_trace_fix (trt_kernels.h)
     enum State { IDLE, ISSUE, WAIT, RESOLVE } state = IDLE;
     uint32_t chunk = 0, s0 = 0, sc_count = 0, n_active = 0, b = 0;
     int cur = 0;
@@ -593,7 +607,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     // Passes are as large as HBM allows: every pass ends in a tail of few, long paths, so fewer and larger passes
     // are faster (back 1080p x 256 spp: 3 passes in 32 GiB 101.4 ms, 1 pass in 93 GB 96.8 ms).  Default budget:
     // three quarters of what is free on the device (the scene is already resident); halved on an allocation failure.
-    const uint64_t bytes_per_path = 2ull * 48 + 16 + 16 + (uint64_t)nl * 48;
+    const uint64_t bytes_per_path = 2ull * 48 + 16 + 16 + (uint64_t)nl * 48 + 4;  // queues, hit, Lacc, shadow queues, redo list
     uint64_t budget = p->mem_budget;
     const bool own_budget = budget == 0;
     if (own_budget) {
@@ -620,7 +634,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         N = (uint64_t)npix * s_chunk;
         // ---- carve the arena: one set of queues per slot
         q16 = (size_t)N * sizeof(f4);
-        per_slot = q16 * (3 * 2 + 1 + 1 + 3 * (size_t)nl);
+        per_slot = q16 * (3 * 2 + 1 + 1 + 3 * (size_t)nl) + (((size_t)N + 3) / 4) * sizeof(f4);  // + the redo list (one index per path)
         const int e = h->arena.ensure(per_slot * (size_t)slots_used);
         if (e == TRT_OK) break;
         if (e != TRT_ENOMEM || !own_budget || budget / 2 < bytes_per_path * npix) return e;
@@ -635,6 +649,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     char* sb = (char*)h->small_buf.p;
     int32_t* d_rows = (int32_t*)sb;
     DeviceStats* d_stats = (DeviceStats*)(sb + rows_bytes + counts_bytes * N_SLOTS);
+    static_assert(sizeof(DeviceStats) <= 128, "the redo counters of the pass slots live behind the statistics");
+    uint32_t* d_redo = (uint32_t*)(sb + rows_bytes + counts_bytes * N_SLOTS + 128);  // one counter per slot
     double* d_acc = (double*)(sb + rows_bytes + counts_bytes * N_SLOTS + stats_bytes);
 
     PassSlot slots[N_SLOTS];
@@ -648,6 +664,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         S.Lacc = take();
         for (uint32_t l = 0; l < (uint32_t)TRT_MAX_LIGHTS; ++l) S.SQ[l] = ShadowQueue{nullptr, nullptr, nullptr};
         for (uint32_t l = 0; l < nl; ++l) { S.SQ[l].sa = take(); S.SQ[l].sb = take(); S.SQ[l].sw = take(); }
+        S.redo.idx = (uint32_t*)base;  // N indices behind the queues
+        S.redo.count = d_redo + k;
         S.d_counts = (uint32_t*)(sb + rows_bytes + counts_bytes * (size_t)k);
         S.host_counts = h->pinned_counts + (size_t)k * (2 * COUNT_ROW + 16);
         S.seq = h->slot_seq[k];
@@ -655,7 +673,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     }
 
     HIPC(hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    HIPC(hipMemsetAsync(d_stats, 0, sizeof(DeviceStats), stream));
+    HIPC(hipMemsetAsync(d_stats, 0, stats_bytes, stream));  // statistics and redo counters
     if (accum_host) HIPC(hipMemcpyAsync(d_acc, accum_host, acc_bytes, hipMemcpyHostToDevice, stream));
     else HIPC(hipMemsetAsync(d_acc, 0, acc_bytes, stream));
 
@@ -731,11 +749,11 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         src.s0 = S.s0;
         tm.begin(TRT_K_TRACE_CLOSEST, S.stream);
         if (S.b == 0) {
-            if (count) launchTraceClosest<true, true>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats);
-            else launchTraceClosest<false, true>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats);
+            if (count) launchTraceClosest<true, true>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats, S.redo);
+            else launchTraceClosest<false, true>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats, S.redo);
         } else {
-            if (count) launchTraceClosest<true, false>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats);
-            else launchTraceClosest<false, false>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats);
+            if (count) launchTraceClosest<true, false>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats, S.redo);
+            else launchTraceClosest<false, false>(h, S.stream, S.spill, src, S.hit, S.n_active, d_stats, S.redo);
         }
         tm.end(S.stream);
         st.launches[TRT_K_TRACE_CLOSEST]++;
@@ -807,8 +825,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
             if (ns > S.n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");
             if (!ns) continue;
             tm.begin(TRT_K_TRACE_SHADOW, S.stream);
-            if (count) launchTraceShadow<true>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee);
-            else launchTraceShadow<false>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee);
+            if (count) launchTraceShadow<true>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee, S.redo);
+            else launchTraceShadow<false>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee, S.redo);
             tm.end(S.stream);
             st.launches[TRT_K_TRACE_SHADOW]++;
             st.rays_shadow += ns;
@@ -954,7 +972,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     const uint32_t n32 = (uint32_t)n;
     const size_t in_bytes = (size_t)n * 3 * sizeof(float);
     const size_t q16 = (size_t)n * sizeof(f4);
-    if (int e = h->io_buf.ensure(2 * in_bytes + 3 * q16 + 256)) return e;
+    if (int e = h->io_buf.ensure(2 * in_bytes + 3 * q16 + 256 + 256 + (size_t)n * sizeof(uint32_t))) return e;  // + redo counter and list
     char* b = (char*)h->io_buf.p;
     f4* ra = (f4*)b;
     f4* rb = ra + n;
@@ -963,9 +981,12 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     float* d_dir = d_org + (size_t)n * 3;
     DeviceStats* d_stats = (DeviceStats*)(d_dir + (size_t)n * 3);
     d_stats = (DeviceStats*)(((uintptr_t)d_stats + 15) & ~(uintptr_t)15);
+    RedoList redo;  // rays for k_trace_fix (trt_kernels.h): the counter sits behind the statistics, the list behind it
+    redo.count = (uint32_t*)((char*)d_stats + 128);
+    redo.idx = (uint32_t*)((char*)d_stats + 256);
     HIPC(hipMemcpy(d_org, org, in_bytes, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_dir, dir, in_bytes, hipMemcpyHostToDevice));
-    HIPC(hipMemset(d_stats, 0, sizeof(DeviceStats)));
+    HIPC(hipMemset(d_stats, 0, 256));
     hipLaunchKernelGGL(k_pack_rays, dim3(std::min<uint32_t>((n32 + 255) / 256, 65536u)), dim3(256), 0, nullptr, d_org, d_dir, ra, rb, n32);
     struct Events {  // destroyed on every path out of this function
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -982,7 +1003,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     RaySource src{};
     src.ra = ra;
     src.rb = rb;
-    launchTraceClosest<true, false>(h, nullptr, (uint32_t*)h->spill.p, src, hit, n32, d_stats);
+    launchTraceClosest<true, false>(h, nullptr, (uint32_t*)h->spill.p, src, hit, n32, d_stats, redo);
     HIPC(hipEventRecord(e1, nullptr));
     HIPC(hipDeviceSynchronize());
     HIPC(hipGetLastError());

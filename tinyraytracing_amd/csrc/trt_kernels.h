@@ -163,6 +163,15 @@ __device__ __forceinline__ void fetchRay(const SceneDev& sc, const RaySource& sr
     else { a = src.ra[i]; b = src.rb[i]; }
 }
 
+// Rays whose result failed the check of traceClosest() (a hit in front of the box of its own leaf; one in ~10^7): the traversal
+// kernels do not store their result but append the queue index here, and k_trace_fix, launched behind every traversal launch,
+// traces them again with the form that checks every triangle hit.  (Inlined into the traversal kernels that form costs 19 VGPRs,
+// i.e. two waves per SIMD.)
+struct RedoList {
+    uint32_t* count;
+    uint32_t* idx;
+};
+
 constexpr uint32_t TRT_REF_IDLE = 0xFFFFFFFFu;  // lane holds no ray        } both have the leaf bit set and
 constexpr uint32_t TRT_REF_DONE = 0xFFFFFFFEu;  // ray finished, not stored } first >= 2^27 - 2: beyond TRT_MAX_TRIS, no builder emits them
 
@@ -229,14 +238,14 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
             if (s < n_pend) {
                 const f4 e = my_pend[s * STRIDE];
                 const float t = e.x / e.y;
-                if (!(t < TRT_T_MIN)) {  // bvh.cpp:189
-                    const int32_t j = (int32_t)f2u(e.z);
-                    const uint32_t leaf = f2u(e.w);
+                if (!(t < TRT_T_MIN) && !(t < e.w)) {  // bvh.cpp:189; and not in front of the box of its leaf (leafEntry(), trt_path.h)
+                    const uint32_t pk = f2u(e.z);  // triangle index | first triangle of its leaf << 8 | triangles in the leaf << 16 (<= 64 triangles here)
+                    const int32_t j = (int32_t)(pk & 0xFFu);
                     const uint32_t fl = f2u(sc.tri_isect[j].c.z);
                     bool take = t < best_t;
                     if (t == best_t && best_tri >= 0) {
                         const bool em = (fl & 1u) != 0, bem = (best_flags & 1u) != 0;
-                        const uint32_t first = TRT_LEAF_FIRST(leaf), cnt = TRT_LEAF_COUNT(leaf);
+                        const uint32_t first = (pk >> 8) & 0xFFu, cnt = pk >> 16;
                         const bool same_leaf = (uint32_t)best_tri >= first && (uint32_t)best_tri < first + cnt;
                         take = same_leaf ? em : (em ? (!bem || j < best_tri) : (!bem && j > best_tri));
                     }
@@ -252,7 +261,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
         const f4* np4 = reinterpret_cast<const f4*>(sc.nodes + ni);  // wave-uniform address
         const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
         if (COUNT && at) n_inner++;
-        float e0, e1;
+        float e0 = 0.0f, e1 = 0.0f;
         const bool h0 = at && boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
         const bool h1 = at && boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
         const uint32_t child[2] = {f2u(q3.x), f2u(q3.y)};
@@ -277,7 +286,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
                 // a full queue among the candidates: empty all of them first (votes on the single compares: their own lane masks)
                 if ((ballotb(ok_det) & ballotb(ok_in) & m_hc & ballotb(n_pend == (uint32_t)TRT_PEND_SLOTS)) != 0ull) flush();
                 if (cand) {
-                    my_pend[n_pend * STRIDE] = mk4(tn, det, u2f(first + k), u2f(ref));
+                    my_pend[n_pend * STRIDE] = mk4(tn, det, u2f((first + k) | (first << 8) | (count << 16)), c == 0 ? e0 : e1);  // + the entry of the leaf's box
                     n_pend++;
                 }
             }
@@ -321,7 +330,7 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
 {
     LdsStack<DEPTH, SPILL> stk;
     stk.lds = smem + threadIdx.x;
@@ -334,8 +343,11 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySo
         f4 a, b;
         fetchRay<PRIMARY>(sc, src, i, a, b);
         const bool any = SHADOW && any_flag;
-        const Hit h = traceClosest<LdsStack<DEPTH, SPILL>, COUNT, NK>(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, n_inner, n_tri, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
-        if (!SHADOW) {
+        const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+        const Hit h = traceClosestPass<LdsStack<DEPTH, SPILL>, COUNT, NK, false>(sc, o, d, stk, n_inner, n_tri, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
+        if (hitInFrontOfItsLeaf(sc, h.t, h.tri, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) {
+            redo.idx[atomicAdd(redo.count, 1u)] = i;  // k_trace_fix traces it again
+        } else if (!SHADOW) {
             hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
         } else if (any ? h.tri < 0 : (h.tri >= 0 && (h.flags >> 8) == light_mat)) {
             const f4 w = sw[i];
@@ -356,7 +368,7 @@ __device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySo
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
 {
     LdsStack<DEPTH, SPILL> stk;
     stk.lds = smem + threadIdx.x;
@@ -396,6 +408,10 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
         const bool can_fill = next < end;
         if (m_work == 0ull || (m_done != 0ull && (uint32_t)__popcll(can_fill ? m_free : m_done) >= sc.refill_min)) {
             if (cur == TRT_REF_DONE) {
+                // a hit in front of the box of its own leaf does not count (leafEntry(), trt_path.h): the result is checked once per ray,
+                // and the (one in ~10^7) rays that end on such a hit go to k_trace_fix instead of being stored
+                if (hitInFrontOfItsLeaf(sc, best_t, best_tri, o, inv)) redo.idx[atomicAdd(redo.count, 1u)] = idx;
+                else
                 storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc, any);
                 cur = TRT_REF_IDLE;
             }
@@ -596,21 +612,21 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueue(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag)
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
 {
     if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats, any_flag, reinterpret_cast<f4*>(smem));
-    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
-    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag);
+    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
+    else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
 }
 
 // PRIMARY: bounce 0 — ray i is the camera ray of path i, generated in registers (K1 of SURVEY.md §7 fused
 // into K2: no primary-ray queue is ever written or read).
 template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
-                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats)
+                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, RedoList redo)
 {
     __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : DEPTH * TRT_TRACE_BLOCK];  // stack, or (uniform walk) the candidate queue
-    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false);
+    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false, redo);
 }
 
 // Shadow test of shade() (pathTracing.cpp:51-58): CLOSEST hit, visible iff
@@ -619,14 +635,42 @@ __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4*
 // write of Lacc needs no atomic and the sum order is fixed.
 template <bool COUNT, int DEPTH, bool SPILL, int IMPL, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
-                                                uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any)
+                                                uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any, RedoList redo)
 {
     __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;
     src.s0 = 0;
-    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false, NK>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u);
+    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false, NK>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u, redo);
+}
+
+// The exact form of the traversal for the rays a traversal launch put on its redo list (see RedoList): one block, launched
+// behind every launch of k_trace_closest / k_trace_shadow of a per-lane driver; it finds an empty list all but once in ~10^7 rays.
+template <bool SHADOW, bool PRIMARY, int NK>
+__global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_fix(SceneDev sc, RaySource src, f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat,
+                                                               f4* __restrict__ Lacc, uint32_t* __restrict__ spill, uint32_t spill_stride, RedoList redo, uint32_t any_flag)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t smem[TRT_LDS_STACK_MAX * TRT_TRACE_BLOCK];
+    const uint32_t n = *redo.count;  // complete: the traversal launch precedes this one on the stream
+    if (n != 0u) {
+        LdsStack<TRT_LDS_STACK_MAX, true> stk;
+        stk.lds = smem + threadIdx.x;
+        stk.spill = spill + threadIdx.x;
+        stk.spill_stride = spill_stride;
+        const bool any = SHADOW && any_flag != 0u;
+        for (uint32_t k = threadIdx.x; k < n; k += TRT_TRACE_BLOCK) {
+            const uint32_t i = redo.idx[k];
+            f4 a, b;
+            fetchRay<PRIMARY>(sc, src, i, a, b);
+            const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+            uint32_t ni = 0, nt = 0;
+            const Hit h = traceClosestPass<LdsStack<TRT_LDS_STACK_MAX, true>, false, NK, true>(sc, o, d, stk, ni, nt, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
+            storeResult<SHADOW>(sc, o, d, h.t, h.tri, h.flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && n != 0u) *redo.count = 0u;  // ready for the next launch
 }
 
 

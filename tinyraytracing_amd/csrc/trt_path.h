@@ -144,7 +144,7 @@ struct SceneDev {
     const trt_bvh_node* nodes;   // the caller's BVH2: the wave-uniform walk of tiny trees (trt_kernels.h, IMPL 0)
     const WideNode* wnodes;      // its 4-wide collapse, exact boxes (NK = 0): trees that are not nested or not compressible
     const CNode* cnodes;         // the same tree with quantised conservative boxes (NK = 1), same node indices
-    const f4* leaf_box;          // NK = 1: exact box of the leaf whose first triangle is i at [2 i] = (lo.xyz, hi.x), [2 i + 1] = (hi.y, hi.z, -, -)
+    const f4* leaf_box;          // for every triangle i the caller's box of its leaf at [2 i] = (lo.xyz, hi.x), [2 i + 1] = (hi.y, hi.z, -, -): leafEntry(), NK = 1 acceptance
     const TriIsect* tri_isect;
     const TriShade* tri_shade;
     const MaterialDev* materials;
@@ -327,6 +327,21 @@ TRT_HD inline bool leafBoxPasses(const SceneDev& sc, uint32_t first, f3 o, f3 in
 // ORDERED = false: the children that are hit are taken in slot order (the first one next, the others pushed) instead of
 // nearest first.  The hit does not depend on the order (see traceClosest); for a shadow ray that nothing occludes neither does
 // the number of nodes visited — its search is bounded by the distance to the light from the start — so the sort buys nothing there.
+// Entry distance of the box of the leaf triangle `tri` lies in (the caller's box of that leaf, leaf_box).  A triangle hit counts
+// only if it does not lie IN FRONT of its leaf's box (t >= entry): for a ray within ~1e-4 rad of a triangle's plane the
+// Moller-Trumbore distance tn / det can come out well in front of the triangle (its barycentrics are computed independently and
+// still say "inside"), i.e. outside every box that contains the triangle.  The reference never produces such a hit — its
+// inside test is applied to the computed point P = o + d t (bvh.cpp:191-198) — and the rule is what makes culling exact: with
+// every accepted t >= the entry of its leaf's box >= the entries of all boxes above it (nested boxes, monotone slab arithmetic),
+// skipping a node whose entry lies beyond the best hit can never skip a hit that would have beaten it.
+TRT_HD inline float leafEntry(const SceneDev& sc, uint32_t tri, f3 o, f3 inv)
+{
+    const f4 a = sc.leaf_box[2 * (size_t)tri], b = sc.leaf_box[2 * (size_t)tri + 1];
+    float e;
+    (void)boxTest(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, e);
+    return e;
+}
+
 template <int NK, class Stack, bool ORDERED = true>
 TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& stk, f3 o, f3 inv, float best_t)
 {
@@ -443,13 +458,18 @@ TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& 
 //                     order independent as: leftmost emissive wins, otherwise the
 //                     rightmost candidate wins.
 // Stack: push(sp, ref) / pop(sp) with sp < scene depth.
-template <class Stack, bool COUNT, int NK = 0>
+// RULE: every triangle hit is tested against leafEntry() on the spot (the exact, slow form).  The kernels run RULE = false and
+// validate the RESULT instead (traceClosest() below): a hit in front of its leaf's box can only matter if it is the one the
+// traversal ends with — while it was the best hit it culled nothing a valid nearer hit lies in (such a hit's boxes all start
+// before it), and once a valid nearer hit replaces it the result is the one the exact form finds.  One box test per ray instead
+// of one per triangle hit; the exact form reruns the (one in ~10^7) rays whose result fails it.
+template <class Stack, bool COUNT, int NK = 0, bool RULE = false>
 // `t_init` bounds the search (only hits STRICTLY nearer count) and `any` stops at the first leaf that yields
 // one: together they make the occlusion test of TRT_FLAG_FIXED_NEE (tri >= 0 <=> something lies in front of t_init).
 // `redo`: t_init is only a hint — a hit in front of it is the closest hit of the whole scene (anything nearer than the
 // bound beats everything beyond it, ties included), and when there is none the search runs again without the bound.
-TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false,
-                               bool redo = false)
+TRT_HD inline Hit traceClosestPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false,
+                                   bool redo = false)
 {
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     Hit best;
@@ -478,7 +498,7 @@ TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
 #endif
                     if (COUNT) n_tri++;
                     float t, un, vn, det;
-                    if (triTest(T, o, d, t, un, vn, det)) {
+                    if (triTest(T, o, d, t, un, vn, det) && !(RULE && t < leafEntry(sc, i, o, inv))) {
                         const uint32_t fl = f2u(T.c.z);
                         if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lun = un; lvn = vn; ldet = det; lflags = fl; }
                     }
@@ -514,6 +534,20 @@ TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
         best.v = best.v / best_det;
     }
     return best;
+}
+
+// does the hit (t, tri) lie in front of the box of tri's leaf?  (leafEntry(): such a hit does not count)
+TRT_HD inline bool hitInFrontOfItsLeaf(const SceneDev& sc, float t, int32_t tri, f3 o, f3 inv)
+{
+    return tri >= 0 && t < leafEntry(sc, (uint32_t)tri, o, inv);
+}
+template <class Stack, bool COUNT, int NK = 0>
+TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false,
+                               bool redo = false)
+{
+    const Hit h = traceClosestPass<Stack, COUNT, NK, false>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo);
+    if (!hitInFrontOfItsLeaf(sc, h.t, h.tri, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) return h;
+    return traceClosestPass<Stack, COUNT, NK, true>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo);
 }
 
 // --------------------------------------------------------------- RNG stream ----

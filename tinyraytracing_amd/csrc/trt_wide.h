@@ -253,6 +253,28 @@ inline WideTree collapseBvhGreedy(const trt_bvh_node* nodes, uint32_t n_nodes)
     return w;
 }
 
+// For every triangle i the caller's box of the leaf it lies in ([2 i] = (lo.xyz, hi.x), [2 i + 1] = (hi.y, hi.z, 0, 0)):
+// leafEntry() of trt_path.h tests a triangle hit against the entry distance of the box of its own leaf.
+inline std::vector<f4> leafBoxesOf(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t n_tris)
+{
+    std::vector<f4> lb((size_t)std::max<uint32_t>(n_tris, 1u) * 2, mk4(0.f, 0.f, 0.f, 0.f));
+    for (uint32_t n = 0; n < n_nodes2; ++n) {
+        const trt_bvh_node& nd = nodes2[n];
+        const uint32_t ref[2] = {nd.child0, nd.child1};
+        const float* lo[2] = {nd.lo0, nd.lo1};
+        const float* hi[2] = {nd.hi0, nd.hi1};
+        for (int k = 0; k < 2; ++k) {
+            if (!(ref[k] & TRT_LEAF_BIT) || TRT_LEAF_COUNT(ref[k]) == 0) continue;
+            const size_t first = TRT_LEAF_FIRST(ref[k]), count = TRT_LEAF_COUNT(ref[k]);
+            for (size_t i = first; i < first + count && i < n_tris; ++i) {
+                lb[2 * i] = mk4(lo[k][0], lo[k][1], lo[k][2], hi[k][0]);
+                lb[2 * i + 1] = mk4(hi[k][1], hi[k][2], 0.f, 0.f);
+            }
+        }
+    }
+    return lb;
+}
+
 // ---- compressed nodes (CNode, trt_path.h) ----------------------------------------------------------------------
 // Same topology and node indices as `w`, boxes quantised to 8 bits per bound inside a per-node frame: origin = the
 // per-axis minimum of the children's lower bounds, scale = the smallest power of two for which every bound fits 0..255.
