@@ -235,7 +235,10 @@ int trt_render_samples(trt_handle* h, const trt_params* p, int32_t sample_begin,
 /* traverseBVH (bvh.cpp:146-175) on a batch of n rays given as HOST arrays
  * org[n][3], dir[n][3].  Outputs (host): t[n] (TRT_INF on miss), tri[n]
  * (post-BVH triangle index, -1 on miss), uv[n][2] (barycentrics of v1,v2).
- * `stats` (optional) receives inner_visits[0]/tri_tests[0] and kernel_ms. */
+ * `stats` (optional) receives inner_visits[0]/tri_tests[0] and kernel_ms.
+ * One rule beyond bvh.cpp's text ("Formulation"): a triangle hit whose distance lies IN FRONT of the box of the
+ * leaf the triangle sits in does not count — for a ray within ~1e-4 rad of a triangle's plane the computed distance can come
+ * out there; the reference rejects such hits through its inside test on the computed point (bvh.cpp:191-198). */
 int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* dir,
                       float* t, int32_t* tri, float* uv, trt_stats* stats);
 
