@@ -61,3 +61,28 @@ def adversarial_rays(scene, n, seed=31):
     bad = np.abs(d).sum(1) == 0
     d[bad] = (1.0, 0.0, 0.0)
     return org, d
+
+
+def grazing_rays(flat, n, seed=5):
+    """Rays that meet a random triangle of the scene at 1e-5 .. 1e-2 rad from its plane, from 0.1 .. 16 units away: the rays for which a
+    Moller-Trumbore distance is least accurate (the case behind the rule 'a hit in front of its own leaf's box does not count')."""
+    f = flat.contents
+    nt = f.n_tris
+    tv = np.ctypeslib.as_array(f.tri_v, shape=(nt * 9,)).reshape(nt, 3, 3).astype(np.float64)
+    rng = np.random.default_rng(seed)
+    ti = rng.integers(0, nt, n)
+    b = rng.random((n, 3))
+    b /= b.sum(1, keepdims=True)
+    P = (tv[ti] * b[:, :, None]).sum(1)
+    e1 = tv[ti, 1] - tv[ti, 0]
+    e2 = tv[ti, 2] - tv[ti, 0]
+    N = np.cross(e1, e2)
+    N /= np.linalg.norm(N, axis=1, keepdims=True) + 1e-300
+    tang = e1 * rng.normal(size=(n, 1)) + e2 * rng.normal(size=(n, 1))
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True) + 1e-300
+    ang = 10.0 ** rng.uniform(-5.2, -2.0, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1))
+    d = tang + N * ang
+    d /= np.linalg.norm(d, axis=1, keepdims=True) + 1e-300
+    o = P - d * 10.0 ** rng.uniform(-1, 1.2, (n, 1))
+    ok = np.isfinite(o).all(1) & np.isfinite(d).all(1) & (np.abs(d).sum(1) > 0)
+    return np.ascontiguousarray(o[ok].astype(np.float32)), np.ascontiguousarray(d[ok].astype(np.float32))

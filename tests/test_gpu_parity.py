@@ -691,3 +691,19 @@ def test_hit_in_front_of_its_leaf_box_does_not_count_on_the_gpu(monkeypatch):
             img, st = T.Renderer(sc, 0).render(p)
             assert_same_image(img, ref, f"flags {flags} impl {impl or 'default'}")
             assert (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
+
+
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_trace_grazing_rays_on_every_wave_driver(name, monkeypatch):
+    """Rays within 1e-5 .. 1e-2 rad of a triangle's plane (raygen.grazing_rays): the closest hits of every wave driver equal the unculled
+    oracle's bit for bit — the case the leaf-box rule exists for; k_trace_fix handles the rays whose result fails the check."""
+    s = get_scene(name, 64, 64)
+    org, dirs = raygen.grazing_rays(s.flat, 150000)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    for impl in ("", "1", "2", "3", "4"):
+        if impl:
+            monkeypatch.setenv("TRT_TRACE_IMPL", impl)
+        else:
+            monkeypatch.delenv("TRT_TRACE_IMPL", raising=False)
+        t1, tri1, uv1 = T.Renderer(s, 0).trace_closest(org, dirs)
+        assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1), (name, impl)
