@@ -204,6 +204,42 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
     }
 }
 
+// The check of a ray's result (a hit in front of the box of its own leaf does not count: leafEntry(), trt_path.h) and the store of
+// that result in ONE memory round trip: the leaf's box is requested together with what the store needs (the winner's record, or the
+// shadow ray's weight and the sample's radiance), and only then is the entry distance formed.  Returns true when the result fails
+// the check: nothing is stored then and the caller puts the ray on the redo list.
+template <bool SHADOW>
+__device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 inv, float best_t, int32_t best_tri, uint32_t best_flags, uint32_t idx, uint32_t pid,
+                                             f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, bool any)
+{
+    const uint32_t tri = best_tri >= 0 ? (uint32_t)best_tri : 0u;
+    const f4 ba = sc.leaf_box[2 * (size_t)tri], bb = sc.leaf_box[2 * (size_t)tri + 1];
+    if (!SHADOW) {
+        const TriIsect T = sc.tri_isect[tri];
+        float e;
+        (void)boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
+        if (best_tri >= 0 && best_t < e) return true;
+        float u = 0.f, v = 0.f;
+        if (best_tri >= 0) {
+            float t, un, vn, det;
+            if (triTest(T, o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
+        }
+        hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
+    } else {
+        const bool vis = any ? best_tri < 0 : (best_tri >= 0 && (best_flags >> 8) == light_mat);
+        f4 w = mk4(0, 0, 0, 0), L = w;
+        if (vis) { w = sw[idx]; L = Lacc[pid]; }
+        float e;
+        (void)boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
+        if (best_tri >= 0 && best_t < e) return true;
+        if (vis) {
+            L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
+            Lacc[pid] = L;
+        }
+    }
+    return false;
+}
+
 // IMPL 0 — wave-uniform evaluation of a tiny BVH (<= 32 inner nodes): no stack, no divergent control
 // flow, no per-lane addresses.  The tree is walked in node-index order (the builders emit parents
 // before children) by the whole wave at once; a per-lane bit mask records which inner nodes the lane's
@@ -410,9 +446,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             if (cur == TRT_REF_DONE) {
                 // a hit in front of the box of its own leaf does not count (leafEntry(), trt_path.h): the result is checked once per ray,
                 // and the (one in ~10^7) rays that end on such a hit go to k_trace_fix instead of being stored
-                if (hitInFrontOfItsLeaf(sc, best_t, best_tri, o, inv)) redo.idx[atomicAdd(redo.count, 1u)] = idx;
-                else
-                storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc, any);
+                if (checkedStore<SHADOW>(sc, o, d, inv, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc, any)) redo.idx[atomicAdd(redo.count, 1u)] = idx;
                 cur = TRT_REF_IDLE;
             }
             if (can_fill) {
