@@ -59,7 +59,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--overlap", action="store_true", help="TRT_FLAG_OVERLAP: two passes in flight (+4-5 %% Mrays/s; per-kernel timings then overlap)")
     ap.add_argument("--fixed-nee", action="store_true", help="TRT_FLAG_FIXED_NEE: unbiased light sampling + occlusion-test shadow rays (not the parity mode; not the headline)")
-    ap.add_argument("--also-overlap", action="store_true", help="after the timed steps, time the same steps again with TRT_FLAG_OVERLAP and report it as with_pass_overlap")
+    ap.add_argument("--no-overlap-extra", action="store_true", help="skip the second timing of the same steps with TRT_FLAG_OVERLAP (reported as with_pass_overlap; what render()/tinyrt "
+                    "ship with).  rocprofv3 runs pass it so that every launch the profiler sees is a non-overlapped one")
+    ap.add_argument("--also-overlap", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--group", type=int, default=0, metavar="N", help="(N=1 process) time the C boundary of the multi-GPU path instead: trt_group_render_device over a "
+                    "group of N entries, all naming device 0 on a one-GPU box (its overhead against trt_render_device is then on record)")
     ap.add_argument("--save-png", default=None)
     return ap.parse_args()
 
@@ -111,8 +115,11 @@ class Bench:
         renderer = T.Renderer(scene, local_rank)
         budget = int(a.mem_gb * (1 << 30))
         fx = T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0
-        flags_time = T.TRT_FLAG_TIMING | base_flags | fx
-        flags_count = T.TRT_FLAG_TIMING | T.TRT_FLAG_COUNT | fx
+        # The timed steps run WITHOUT TRT_FLAG_TIMING (two hipEventRecords per launch, ~60 launches per step: at one rank of eight a
+        # step is ~12 ms and they show); per-kernel times come from ONE extra step with the events on, after the timed region.
+        flags_time = base_flags | fx
+        flags_prof = T.TRT_FLAG_TIMING | base_flags | fx
+        flags_count = T.TRT_FLAG_COUNT | fx
         p_rank = D.shard_params(width, height, spp, seed, rank, world, flags=flags_time, mem_budget=budget)
         nrows = len(T.rows_selected(p_rank))
         out = torch.empty((nrows, width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -129,8 +136,6 @@ class Bench:
             step(flags_time)
         self.sync()
         t_begin = time.perf_counter()
-        kernel_ms = [0.0] * 8
-        launches = [0] * 8
         rays_rank = 0
         render_ms = 0.0
         st = st_count
@@ -138,16 +143,19 @@ class Bench:
             img, st = step(flags_time)
             rays_rank += st.rays
             render_ms += st.render_ms
-            for k in range(8):
-                kernel_ms[k] += st.kernel_ms[k]
-                launches[k] += st.launches[k]
         self.sync()
         elapsed = time.perf_counter() - t_begin
+        # the profiling step: the same render once more with hipEvents around every launch (on the launch stream, inside the
+        # library); its per-kernel sums are scaled to `steps` so that every per-step figure below keeps its meaning
+        img, st_prof = step(flags_prof)
+        self.sync()
+        kernel_ms = [st_prof.kernel_ms[k] * steps for k in range(8)]
+        launches = [st_prof.launches[k] * steps for k in range(8)]
         # --also-overlap: beside the contract's number, the same steps with two sample passes in flight
         # (TRT_FLAG_OVERLAP, what render()/tinyrt use).  Not `value`: per-kernel hipEvent times of overlapping passes
         # contain each other.  Off by default so that a rocprofv3 run of the default command sees the timed launches only.
         overlap_extra = None
-        if world == 1 and also_overlap and not (base_flags & T.TRT_FLAG_OVERLAP):
+        if world == 1 and also_overlap and not (base_flags & T.TRT_FLAG_OVERLAP) and spp >= 2:
             step(T.TRT_FLAG_OVERLAP | fx)
             self.sync()
             t_ov = time.perf_counter()

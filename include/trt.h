@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TRT_ABI_VERSION 3
+#define TRT_ABI_VERSION 4
 
 /* error codes */
 #define TRT_OK 0
@@ -194,9 +194,11 @@ typedef struct trt_stats {
     uint32_t passes;            /* sample chunks the render was split into */
     uint32_t max_bounces;       /* deepest path vertex index reached */
     uint64_t rows_rendered;     /* rows in the packed output */
-    uint32_t inner_node_bytes;  /* bytes one inner-node visit fetches: 64 (the caller's BVH2 node: two boxes + refs, tiny scenes)
-                                 * or 128 (its 4-wide collapse: four boxes + refs) */
-    uint32_t reserved;
+    uint32_t inner_node_bytes;  /* bytes one inner-node visit fetches: 64 (the caller's BVH2 node: two boxes + refs, tiny scenes),
+                                 * 128 (its exact 4-wide collapse: four boxes + refs) or 80 (its 8-wide collapse with quantised boxes) */
+    uint32_t redo_rays;         /* rays whose traversal result failed the check made when it is stored (a hit in front of the box of its
+                                 * own leaf, or — 8-wide nodes — on a leaf whose exact box the ray misses) and that were traced again in
+                                 * the exact form: a handful per 10^7 on padded trees; a large number says the slow path is carrying the render */
 } trt_stats;
 
 typedef struct trt_handle trt_handle;
@@ -237,8 +239,10 @@ int trt_render_samples(trt_handle* h, const trt_params* p, int32_t sample_begin,
  * (post-BVH triangle index, -1 on miss), uv[n][2] (barycentrics of v1,v2).
  * `stats` (optional) receives inner_visits[0]/tri_tests[0] and kernel_ms.
  * One rule beyond bvh.cpp's text ("Formulation"): a triangle hit whose distance lies IN FRONT of the box of the
- * leaf the triangle sits in does not count — for a ray within ~1e-4 rad of a triangle's plane the computed distance can come
- * out there; the reference rejects such hits through its inside test on the computed point (bvh.cpp:191-198). */
+ * leaf the triangle sits in — by more than a tolerance of 2^-16 relative plus 2^-17 of the scene's largest coordinate — does
+ * not count: for a ray within ~1e-4 rad of a triangle's plane the computed distance can come out there; the reference rejects
+ * such hits through its inside test on the computed point (bvh.cpp:191-198).  The tolerance keeps the rule off honest hits:
+ * leaf boxes need NOT be padded (a triangle lying on a face of its leaf's box is found), at any coordinate magnitude. */
 int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* dir,
                       float* t, int32_t* tri, float* uv, trt_stats* stats);
 
@@ -252,7 +256,10 @@ void trt_destroy(trt_handle* h);
  * ncclCommInitAll :236) brings the packed stripes to devices[0], which un-interleaves them.  The random streams are keyed
  * by the global (pixel, sample), so the image is bit-identical to trt_render's for every n and every row_block.
  * RCCL is loaded (dlopen librccl.so.1) by trt_group_create only when the group spans more than one DISTINCT device;
- * a group whose entries name the same device several times (a rehearsal on a one-GPU box) gathers with device copies. */
+ * a group whose entries name the same device several times (a rehearsal on a one-GPU box) gathers with device copies.
+ * TRT_GROUP_FORCE_RCCL=1 in the environment at trt_group_create (a test switch) sends a group of ONE device through the
+ * RCCL route as well — communicator of size 1, ncclGather to itself — so that the dlopen, the symbol bindings, the data type
+ * constant and the stream ordering run on a one-GPU box.  Every device has a host thread of its own for the group's life. */
 typedef struct trt_group trt_group;
 int trt_group_create(const trt_scene* scene, int n_devices, const int* devices, trt_group** out);
 /* p: as for trt_render (tile, spp, seed, flags); p->row_block (>= 1; 0 = 8) is the stripe height, row_mod / row_rem are
@@ -260,6 +267,9 @@ int trt_group_create(const trt_scene* scene, int n_devices, const int* devices, 
  * counted from image row 0).  out_rgb_host: (y1-y0) * (x1-x0) * 3 floats.  stats (optional): rays / launches / kernel_ms summed
  * over the devices, render_ms = the slowest device's, plus gather_ms = gather + un-interleave on devices[0]. */
 int trt_group_render(trt_group* g, const trt_params* p, float* out_rgb_host, trt_stats* stats, double* gather_ms);
+/* The same with the image left in DEVICE memory of devices[0] (out_rgb_dev0: (y1-y0) * (x1-x0) * 3 floats there; nothing crosses
+ * PCIe): what a caller that goes on working on the GPU links, and what bench.py --group times. */
+int trt_group_render_device(trt_group* g, const trt_params* p, float* out_rgb_dev0, trt_stats* stats, double* gather_ms);
 int trt_group_size(const trt_group* g);
 void trt_group_destroy(trt_group* g);
 

@@ -152,4 +152,31 @@ static inline TRT_HD float trt_pow01(float x, float y)
     return trt_expf_neg(y * trt_logf(x));
 }
 
+/* ---- the leaf-box rule with a tolerance (DESIGN.md "Formulation") ----------------------------------------------------
+ * A triangle hit at distance t counts iff NOT t < trt_leaf_floor(e, alpha), e = the slab entry distance of the caller's box
+ * of the leaf the triangle lies in.  The rule exists to make ordered, culled traversal return the unculled traversal's
+ * hit for EVERY input (for rays within ~1e-4 rad of a triangle's plane Moller-Trumbore's tn/det can come out far in
+ * front of the triangle and of every box around it); it is not meant to judge hits, so the floor lies well below the
+ * entry: 2^-16 relative plus alpha = 2^-17 of the scene's largest coordinate.  That absorbs the rounding differences
+ * between the two computations of one distance — a triangle lying ON a face of its (unpadded) leaf box, coordinates of
+ * 4e4 where one ulp exceeds the reference's 0.001 pad — which a bare `t < e` rejected about half of the time.
+ * Monotone under rounding: e -> e * k is non-decreasing for a fixed k > 0 (negative products stay <= 0 <= positive
+ * ones), x -> x - alpha is non-decreasing; so for nested boxes floor(entry of the leaf) >= floor(entry of any box above). */
+#define TRT_LEAF_KPOS 0.9999847412109375f  /* 1 - 2^-16 */
+#define TRT_LEAF_KNEG 1.0000152587890625f  /* 1 + 2^-16 */
+static inline TRT_HD float trt_leaf_floor(float e, float alpha)
+{
+    return e * (e < 0.0f ? TRT_LEAF_KNEG : TRT_LEAF_KPOS) - alpha;
+}
+/* alpha of a scene whose root boxes reach |coordinate| <= m (exact: a power-of-two scaling). */
+static inline TRT_HD float trt_leaf_alpha(float m) { return m * 7.62939453125e-6f; /* 2^-17 */ }
+/* Culling bound that goes with the rule: a node whose entry distance e satisfies e > trt_cull_bound(b, alpha) holds no hit
+ * that counts and is <= b, for b >= 0: then e > 0, and trt_leaf_floor(e) >= (e (1 - 2^-16)(1 - u) - alpha)(1 - u) with
+ * e >= (b + 2 alpha)(1 + 2^-14)(1 - u)^2 (u = 2^-24), i.e. > b (1 + 2.9 * 2^-16) + alpha > b; every hit below the node
+ * that counts has t >= floor(entry of its leaf) >= floor(e) > b.  (b = +inf: never culls.) */
+static inline TRT_HD float trt_cull_bound(float b, float alpha)
+{
+    return (b + (alpha + alpha)) * 1.00006103515625f;  /* 1 + 2^-14 */
+}
+
 #endif /* TRT_PRIMS_H */

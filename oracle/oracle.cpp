@@ -93,8 +93,15 @@ struct Tri {
 struct SceneView {
     const trt_scene* s;
     std::vector<Tri> tris;
+    float leaf_alpha = 0.0f;  // absolute part of the leaf-box rule's tolerance (trt_prims.h): 2^-17 of the largest |coordinate| of the root's child boxes
     explicit SceneView(const trt_scene* sc) : s(sc)
     {
+        if (sc->n_nodes) {
+            const trt_bvh_node& r = sc->nodes[0];
+            float m = 0.0f;
+            for (int a = 0; a < 3; ++a) m = fmaxf(m, fmaxf(fmaxf(fabsf(r.lo0[a]), fabsf(r.hi0[a])), fmaxf(fabsf(r.lo1[a]), fabsf(r.hi1[a]))));
+            leaf_alpha = trt_leaf_alpha(m);
+        }
         tris.resize(sc->n_tris);
         for (uint32_t i = 0; i < sc->n_tris; ++i) {
             const float* p = sc->tri_v + (size_t)i * 9;
@@ -178,11 +185,14 @@ struct Tracer {
 
     // interactBVHNode (bvh.cpp:211-229): scan in index order; replace when
     // strictly nearer, or equally near and emissive.
-    // `entry`: the entry distance of the leaf's own box.  A hit IN FRONT of the box of its leaf does not count: for a ray within
+    // `entry`: the entry distance of the leaf's own box.  A hit IN FRONT of the box of its leaf — by more than the tolerance of
+    // trt_leaf_floor (trt_prims.h: 2^-16 relative + 2^-17 of the scene's largest coordinate) — does not count: for a ray within
     // ~1e-4 rad of a triangle's plane the Moller-Trumbore distance can come out well in front of the triangle while its
     // barycentrics still say "inside"; the reference applies its inside test to the computed point P = o + d t
     // (bvh.cpp:191-198) and never produces such a hit.  (It is also what makes the kernels' culled traversal return this
-    // unculled one's result for every input: an accepted t is never smaller than the entry of any box around its triangle.)
+    // unculled one's result for every input: a hit that counts is never nearer than the floor of any box around its triangle.)
+    // The tolerance keeps the rule off honest hits: a triangle ON a face of its leaf's box (unpadded trees, coordinates where
+    // the 0.001 pad of bvh.cpp:31-40 is below one ulp) has entry and tn / det equal up to rounding.
     Hit leafScan(uint32_t first, uint32_t count, V3 o, V3 d, float entry = -TRT_INF) const
     {
         Hit res;
@@ -190,7 +200,7 @@ struct Tracer {
             float t, u, v;
             if (cnt) cnt->tests[kind]++;
             if (!triTest(sv.tris[i], o, d, t, u, v)) continue;
-            if (t < entry) continue;
+            if (t < trt_leaf_floor(entry, sv.leaf_alpha)) continue;
             if ((t == res.t && sv.emissive((int32_t)i)) || t < res.t) {
                 res.t = t;
                 res.tri = (int32_t)i;
@@ -225,7 +235,7 @@ struct Tracer {
             for (uint32_t i = TRT_LEAF_FIRST(ref); i < TRT_LEAF_FIRST(ref) + TRT_LEAF_COUNT(ref); ++i) {
                 float t, u, v;
                 if (cnt) cnt->tests[kind]++;
-                if (triTest(sv.tris[i], o, d, t, u, v) && !(t < entry) && t < t_max) found = true;  // leafScan's rule
+                if (triTest(sv.tris[i], o, d, t, u, v) && !(t < trt_leaf_floor(entry, sv.leaf_alpha)) && t < t_max) found = true;  // leafScan's rule
             }
             return found;
         }
@@ -330,15 +340,16 @@ struct Vertex {
     V3 off;  // TRT_FLAG_RAY_OFFSET: eps * geometric normal of the hit triangle (zero otherwise)
 };
 
-// EXPERIMENT (tools/rank_ref_png.py --variants): estimator variants tried against the reference's `back` snapshots, which predate
-// the committed indirect term.  Never set by tests of the parity path.
-static bool g_experiment_no_rr_div = false;
 
 struct PathTracer {
     const SceneView& sv;
     Counters& cnt;
     Tracer closest{sv, &cnt, 0};
     Tracer shadow{sv, &cnt, 1};
+
+    // EXPERIMENT (ORACLE_MODE_EXPERIMENT_NO_RR_DIV, an explicit bit of oracle_render's `mode`): the estimator without the 1 / P_RR of
+    // pathTracing.cpp:84, tried against the reference's `back` snapshots.  Never set by tests of the parity path.
+    bool experiment_no_rr_div = false;
 
     PathTracer(const SceneView& v, Counters& c) : sv(v), cnt(c) {}
 
@@ -470,7 +481,7 @@ struct PathTracer {
                         type_out = type;
                         if (type != TRT_RAY_INVALID) {
                             const V3 w = (type == TRT_RAY_TRANSMISSION) ? ld(vx.m->Tr) : vx.Kd;  // Q8
-                            beta = g_experiment_no_rr_div ? beta * w : (beta * w) / TRT_P_RR;
+                            beta = experiment_no_rr_div ? beta * w : (beta * w) / TRT_P_RR;
                             o = rayOrigin(vx, nd);  // Q6: no offset unless TRT_FLAG_RAY_OFFSET
                             d = nd;
                             prev_type = type;
@@ -575,7 +586,8 @@ extern "C" {
 
 int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats, int threads, int mode)
 {
-    g_experiment_no_rr_div = std::getenv("ORACLE_EXPERIMENT_NO_RR_DIV") != nullptr;
+    const bool no_rr_div = (mode & ORACLE_MODE_EXPERIMENT_NO_RR_DIV) != 0;
+    mode &= ~ORACLE_MODE_EXPERIMENT_NO_RR_DIV;
     if (int e = checkParams(scene, p)) return e;
     if (!out_rgb) return TRT_EINVAL;
     const SceneView sv(scene);
@@ -592,6 +604,7 @@ int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, o
         PathTracer pt(sv, cnt);
         pt.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) != 0;
         pt.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) != 0;
+        pt.experiment_no_rr_div = no_rr_div;
 #pragma omp for schedule(dynamic, 1)
         for (long r = 0; r < (long)rows.size(); ++r) {
             const int i = rows[(size_t)r];

@@ -26,6 +26,9 @@ typedef struct oracle_stats {
 
 #define ORACLE_MODE_ITERATIVE 0 /* beta-weighted loop: the bit-parity target of the HIP path */
 #define ORACLE_MODE_RECURSIVE 1 /* literal recursion of shade() (pathTracing.cpp:3-102) */
+#define ORACLE_MODE_EXPERIMENT_NO_RR_DIV 0x100 /* or-ed into `mode` (iterative form): the estimator WITHOUT the 1 / P_RR of pathTracing.cpp:84 — an
+                                                * experiment of tests/test_ref_png.py against the reference's older `back` snapshots, never the parity path.
+                                                * An explicit argument: no environment variable can change what this library computes. */
 
 /* main.cpp:80-113 restated.  Same trt_params semantics as trt_render (tile,
  * row interleave, packed float output).  threads <= 0 -> all cores. */

@@ -9,15 +9,22 @@
 
 #include "trt_path.h"
 #include "trt_wide.h"
+#include "trt_oct_build.h"
 
 using namespace trtd;
 
 namespace {
-int g_node_kind = 0;  // hostsim_set_node_kind: what trt_create picks by default (exact wide nodes); 1 = compressed nodes where the tree allows them
+int g_node_kind = 0;  // hostsim_set_node_kind: 0 = exact 4-wide nodes; 1 = the 8-wide compressed nodes of trt_oct.h where the tree allows them
 struct ArrayStack {
     uint32_t s[1024];
     void push(int sp, uint32_t v) { s[sp] = v; }
     uint32_t pop(int sp) const { return s[sp]; }
+};
+
+struct OctArrayStack {
+    OctGroup s[256];
+    void push(int sp, OctGroup g) { s[sp] = g; }
+    OctGroup pop(int sp) const { return s[sp]; }
 };
 
 struct HostScene {
@@ -30,9 +37,9 @@ struct HostScene {
     std::vector<LightDev> lights;
     std::vector<LightTriDev> ltris;
     WideTree wide;
-    CompressedTree comp;
+    OctTree oct;
     std::vector<f4> leaf_boxes;
-    int nk = 0;  // node kind the traversal walks: 0 exact wide nodes (trt_create's default), 1 compressed (TRT_NODE_KIND=1)
+    int nk = 0;  // node kind the traversal walks: 0 exact 4-wide nodes, 1 compressed 8-wide nodes (TRT_NODE_KIND)
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
     {
@@ -63,11 +70,14 @@ struct HostScene {
         wide = collapseBvh(s->nodes, s->n_nodes);
         sc.wnodes = wide.nodes.data();
         sc.n_wnodes = (uint32_t)wide.nodes.size();
-        comp = compressWide(wide, s->nodes, s->n_nodes, s->n_tris);
-        sc.cnodes = comp.ok ? comp.nodes.data() : nullptr;
+        if (g_node_kind != 0) oct = buildOct(s->nodes, s->n_nodes, s->n_tris, isect.data());
+        sc.onodes = oct.ok ? oct.nodes.data() : nullptr;
+        sc.tri_trav = oct.ok ? oct.tri_trav.data() : nullptr;
+        sc.n_onodes = (uint32_t)oct.nodes.size();
         leaf_boxes = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris);
         sc.leaf_box = leaf_boxes.data();
-        nk = (comp.ok && g_node_kind != 0) ? 1 : 0;
+        sc.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
+        nk = (oct.ok && g_node_kind != 0) ? 1 : 0;
         sc.tri_isect = isect.data();
         sc.tri_shade = shade.data();
         sc.materials = mats.data();
@@ -100,11 +110,21 @@ extern "C" int hostsim_set_node_kind(int nk)
     g_node_kind = nk;
     return old;
 }
-// 1 when `s` can be walked with compressed nodes (nested, finite boxes)
+// 1 when `s` can be walked with the compressed 8-wide nodes (nested, finite boxes, leaves of <= 3 triangles)
 extern "C" int hostsim_compressible(const trt_scene* s)
 {
-    const WideTree w = collapseBvh(s->nodes, s->n_nodes);
-    return compressWide(w, s->nodes, s->n_nodes, s->n_tris).ok ? 1 : 0;
+    std::vector<TriIsect> isect(s->n_tris);
+    for (uint32_t i = 0; i < s->n_tris; ++i) isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, s->tri_mat[i], s->materials[s->tri_mat[i]].is_emissive != 0);
+    return buildOct(s->nodes, s->n_nodes, s->n_tris, isect.data()).ok ? 1 : 0;
+}
+// nodes / levels of the oct tree (0 when it cannot be built)
+extern "C" int hostsim_oct_info(const trt_scene* s, uint64_t out[3])
+{
+    std::vector<TriIsect> isect(s->n_tris);
+    for (uint32_t i = 0; i < s->n_tris; ++i) isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, s->tri_mat[i], s->materials[s->tri_mat[i]].is_emissive != 0);
+    const OctTree t = buildOct(s->nodes, s->n_nodes, s->n_tris, isect.data());
+    out[0] = t.ok ? t.nodes.size() : 0; out[1] = t.levels; out[2] = t.tri_trav.size();
+    return t.ok ? 0 : 1;
 }
 
 extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* out_rgb, uint64_t rays[3])
@@ -130,6 +150,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : r_cam, r_sh, r_ind)
     for (long pl = 0; pl < (long)npix; ++pl) {
         ArrayStack stk;
+        OctArrayStack ostk;
         uint32_t ni = 0, nt = 0;
         double acc[3] = {0, 0, 0};
         for (uint32_t sidx = 0; sidx < S; ++sidx) {
@@ -148,7 +169,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
             r_cam++;
             for (;;) {
                 // k_trace_closest
-                const Hit h = hs.nk ? traceClosest<ArrayStack, false, 1>(hs.sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni, nt)
+                const Hit h = hs.nk ? traceClosestOct<OctArrayStack, ArrayStack, false>(hs.sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), ostk, stk, ni, nt)
                                     : traceClosest<ArrayStack, false, 0>(hs.sc, mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), stk, ni, nt);
                 const f4 hit4 = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
                 // k_shade
@@ -163,7 +184,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
                     const f3 w = cx.beta * contrib;
                     r_sh++;
                     // k_trace_shadow
-                    const Hit sh = hs.nk ? traceClosest<ArrayStack, false, 1>(hs.sc, rayOrigin(cx, wo), wo, stk, ni, nt, t_max, fixed, !fixed)
+                    const Hit sh = hs.nk ? traceClosestOct<OctArrayStack, ArrayStack, false>(hs.sc, rayOrigin(cx, wo), wo, ostk, stk, ni, nt, t_max, fixed, !fixed)
                                          : traceClosest<ArrayStack, false, 0>(hs.sc, rayOrigin(cx, wo), wo, stk, ni, nt, t_max, fixed, !fixed);
                     if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)hs.sc.lights[li].mat)) L = L + w;
                 }
@@ -194,8 +215,9 @@ extern "C" int hostsim_trace(const trt_scene* s, uint64_t n, const float* org, c
 #pragma omp parallel for schedule(static) reduction(+ : ci, ct)
     for (long long i = 0; i < (long long)n; ++i) {
         ArrayStack stk;
+        OctArrayStack ostk;
         uint32_t ni = 0, nt = 0;
-        const Hit h = hs.nk ? traceClosest<ArrayStack, true, 1>(hs.sc, ld3(org + i * 3), ld3(dir + i * 3), stk, ni, nt)
+        const Hit h = hs.nk ? traceClosestOct<OctArrayStack, ArrayStack, true>(hs.sc, ld3(org + i * 3), ld3(dir + i * 3), ostk, stk, ni, nt)
                             : traceClosest<ArrayStack, true, 0>(hs.sc, ld3(org + i * 3), ld3(dir + i * 3), stk, ni, nt);
         t[i] = h.t;
         tri[i] = h.tri;

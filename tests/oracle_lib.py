@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 
 MODE_ITERATIVE, MODE_RECURSIVE = 0, 1
+MODE_EXPERIMENT_NO_RR_DIV = 0x100  # or-ed into `mode`: oracle.h
 TRACE_REFERENCE, TRACE_BRUTE = 0, 1
 
 

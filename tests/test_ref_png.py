@@ -136,11 +136,12 @@ def test_back_snapshots_predate_the_russian_roulette_compensation(monkeypatch):
     s = get_scene("back", 1024, 1024)
     p = T.make_params(1024, 1024, 8, SEEDS["back"])
     committed = _oracle_render("back", 8)
-    monkeypatch.setenv("ORACLE_EXPERIMENT_NO_RR_DIV", "1")
-    variant = O.render(s.flat, p)[0]
+    variant = O.render(s.flat, p, mode=O.MODE_ITERATIVE | O.MODE_EXPERIMENT_NO_RR_DIV)[0]  # an explicit mode bit, not an environment variable
+    monkeypatch.setenv("ORACLE_EXPERIMENT_NO_RR_DIV", "1")  # ... which the library no longer reads
+    tile = T.make_params(1024, 1024, 2, 3, tile=(500, 500, 516, 508))
+    with_env = O.render(s.flat, tile)[0]
     monkeypatch.delenv("ORACLE_EXPERIMENT_NO_RR_DIV")
-    assert np.array_equal(O.render(s.flat, T.make_params(1024, 1024, 1, 3, tile=(500, 500, 516, 508)))[0],
-                          O.render(s.flat, T.make_params(1024, 1024, 1, 3, tile=(500, 500, 516, 508)))[0])  # the switch is off again
+    assert np.array_equal(with_env, O.render(s.flat, tile)[0])
     for fixture in ("back_image10.png", "back_image10-0.png"):
         png = _png(fixture)
         med_c, _, corr_c = _compare(committed, png)

@@ -281,6 +281,19 @@ class GroupRenderer:
             raise TrtError(f"trt_group_render failed ({rc}): {self._lib.trt_last_error().decode()}")
         return out, st, gms.value
 
+    def render_into(self, params, out_tensor):
+        """trt_group_render_device: the image stays on devices[0] (a contiguous float32 torch tensor there with tile rows * tile_w * 3
+        elements).  -> (Stats summed over the devices, gather + un-interleave ms)."""
+        th, tw = params.y1 - params.y0, params.x1 - params.x0
+        if out_tensor.numel() < th * tw * 3 or str(out_tensor.dtype) != "torch.float32" or not out_tensor.is_cuda or not out_tensor.is_contiguous():
+            raise TrtError("render_into: need a contiguous float32 device tensor with tile rows * tile_w * 3 elements")
+        st = Stats()
+        gms = C.c_double(0.0)
+        rc = self._lib.trt_group_render_device(self._g, C.byref(params), C.c_void_p(out_tensor.data_ptr()), C.byref(st), C.byref(gms))
+        if rc != 0:
+            raise TrtError(f"trt_group_render_device failed ({rc}): {self._lib.trt_last_error().decode()}")
+        return st, gms.value
+
     def close(self):
         if getattr(self, "_g", None):
             self._lib.trt_group_destroy(self._g)

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-TRT_ABI_VERSION = 3
+TRT_ABI_VERSION = 4
 TRT_INF = 114514.0
 TRT_FLAG_TIMING = 1
 TRT_FLAG_COUNT = 2
@@ -74,7 +74,7 @@ class Stats(C.Structure):
                 ("shaded_hits", C.c_uint64), ("inner_visits", C.c_uint64 * 2), ("tri_tests", C.c_uint64 * 2), ("wave_steps", C.c_uint64 * 2),
                 ("launches", C.c_uint64 * TRT_MAX_KERNELS), ("kernel_ms", C.c_double * TRT_MAX_KERNELS),
                 ("render_ms", C.c_double), ("passes", C.c_uint32), ("max_bounces", C.c_uint32),
-                ("rows_rendered", C.c_uint64), ("inner_node_bytes", C.c_uint32), ("reserved", C.c_uint32)]
+                ("rows_rendered", C.c_uint64), ("inner_node_bytes", C.c_uint32), ("redo_rays", C.c_uint32)]
 
     @property
     def rays(self):
@@ -83,7 +83,7 @@ class Stats(C.Structure):
 
 # the symbols include/trt.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = ["trt_rows_selected", "trt_create", "trt_render", "trt_render_device", "trt_render_samples", "trt_trace_closest",
-               "trt_destroy", "trt_last_error", "trt_abi_version", "trt_group_create", "trt_group_render", "trt_group_size", "trt_group_destroy"]
+               "trt_destroy", "trt_last_error", "trt_abi_version", "trt_group_create", "trt_group_render", "trt_group_render_device", "trt_group_size", "trt_group_destroy"]
 HOST_SYMBOLS = ["trth_scene_load", "trth_scene_load_opts", "trth_scene_drop_tris", "trth_scene_add_soup", "trth_scene_add_blob",
                 "trth_scene_build", "trth_scene_flat", "trth_scene_info", "trth_scene_light_area",
                 "trth_scene_material_name", "trth_scene_free", "trth_tonemap", "trth_write_png",
@@ -173,6 +173,7 @@ def load_hip():
     lib.trt_destroy.restype = None
     lib.trt_group_create.argtypes = [C.POINTER(SceneFlat), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
     lib.trt_group_render.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(Stats), C.POINTER(C.c_double)]
+    lib.trt_group_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats), C.POINTER(C.c_double)]
     lib.trt_group_size.argtypes = [C.c_void_p]
     lib.trt_group_destroy.argtypes = [C.c_void_p]
     lib.trt_group_destroy.restype = None

@@ -11,7 +11,9 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -19,6 +21,7 @@
 #include "trt.h"
 #include "trt_kernels.h"
 #include "trt_wide.h"
+#include "trt_oct_build.h"
 
 using namespace trtd;
 
@@ -53,6 +56,10 @@ constexpr uint32_t PAIR_ROW = COUNT_ROW - 2;
 static_assert(1 + TRT_MAX_LIGHTS <= (int)PAIR_ROW, "counter rows overlap");
 inline unsigned long long* pairCounter(uint32_t* d_counts, uint32_t b) { return reinterpret_cast<unsigned long long*>(d_counts + (size_t)PAIR_ROW * COUNT_STRIDE) + b; }
 constexpr uint32_t MAX_BVH_DEPTH = 256;
+// node kind of the persistent traversal kernels when the tree qualifies for both (DESIGN.md §4.1 has the A/B)
+#ifndef TRT_DEFAULT_NODE_KIND
+#define TRT_DEFAULT_NODE_KIND 1
+#endif
 
 struct DevBuf {
     void* p = nullptr;
@@ -86,8 +93,9 @@ struct trt_handle {
     const void* lds_image = nullptr;  // the tables of shade_tabs, packed
     uint32_t lds_image_bytes = 0;
     uint32_t lds_tab[5] = {0, 0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles / (tiny scenes) shading triangles that k_shade stages in LDS
-    int trace_impl = 3;       // wave driver of the traversal kernels (0 uniform tiny-tree, 1 static, 2 while-while, 3 scheduler)
-    int node_kind = 0;        // what the per-lane traversal walks: 0 exact 128-B wide nodes, 1 compressed 64-B nodes (trt_path.h CNode)
+    int trace_impl = 3;       // wave driver of the traversal kernels (0 wave-uniform walk of a tiny tree, 3 persistent waves + step scheduler)
+    int node_kind = 0;        // what the persistent traversal kernels walk: 0 exact 128-B 4-wide nodes, 1 compressed 80-B 8-wide nodes (trt_oct.h)
+    uint32_t oct_levels = 0;  // nodes on the longest root path of the oct tree
     // Grid of the traversal kernels for a queue of n rays.  A persistent wave refills finished lanes from its own slice
     // of the queue, which only pays when the slice holds several batches: aim for rays_per_wave rays per wave, but do
     // not go below the fill_blocks that fill the chip's wave slots, nor above one block per 256 rays.
@@ -293,25 +301,23 @@ struct Timer {
         else if (h->depth <= 16) LAUNCH(16, false, IMPL, NK);                \
         else LAUNCH(TRT_LDS_STACK_MAX, true, IMPL, NK);                      \
     } while (0)
-#define TRT_BY_IMPL(LAUNCH, NK)                                              \
+// the oct tree needs one 8-byte entry per level below the root
+constexpr uint32_t OCT_LDS_SHALLOW = 8, OCT_LDS_DEEP = 12;
+#define TRT_BY_OCT_DEPTH(LAUNCH)                                             \
     do {                                                                     \
-        if (h->trace_impl == 1) TRT_BY_DEPTH(LAUNCH, 1, NK);                 \
-        else if (h->trace_impl == 2) TRT_BY_DEPTH(LAUNCH, 2, NK);            \
-        else if (h->trace_impl == 4) TRT_BY_DEPTH(LAUNCH, 4, NK);            \
-        else TRT_BY_DEPTH(LAUNCH, 3, NK);                                    \
+        if (h->oct_levels <= OCT_LDS_SHALLOW + 1) LAUNCH(8, false, 3, 1);    \
+        else LAUNCH(12, true, 3, 1);                                         \
     } while (0)
-
-// Behind every traversal launch of a per-lane driver: k_trace_fix (one block) traces the rays of the launch's redo list again in the
+// Behind every traversal launch of a per-lane driver: k_trace_fix (a few blocks) traces the rays of the launch's redo list again in the
 // exact form (trt_kernels.h, RedoList).  The wave-uniform walk applies the rule on the spot and has no list.
 template <bool COUNT, bool PRIMARY>
 void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats, RedoList redo)
 {
     const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->trace_impl == 0) { TRT_LAUNCH_CLOSEST(1, false, 0, 0); return; }
-    if (h->node_kind == 1) TRT_BY_IMPL(TRT_LAUNCH_CLOSEST, 1);
-    else TRT_BY_IMPL(TRT_LAUNCH_CLOSEST, 0);
-    if (h->node_kind == 1) hipLaunchKernelGGL((k_trace_fix<false, PRIMARY, 1>), dim3(1), b, 0, stream, h->sc, src, hit, (const f4*)nullptr, 0u, (f4*)nullptr, spill, SPILL_STRIDE, redo, 0u);
-    else hipLaunchKernelGGL((k_trace_fix<false, PRIMARY, 0>), dim3(1), b, 0, stream, h->sc, src, hit, (const f4*)nullptr, 0u, (f4*)nullptr, spill, SPILL_STRIDE, redo, 0u);
+    if (h->node_kind == 1) TRT_BY_OCT_DEPTH(TRT_LAUNCH_CLOSEST);
+    else TRT_BY_DEPTH(TRT_LAUNCH_CLOSEST, 3, 0);
+    hipLaunchKernelGGL((k_trace_fix<false, PRIMARY, 0>), dim3(TRT_FIX_BLOCKS), b, 0, stream, h->sc, src, hit, (const f4*)nullptr, 0u, (f4*)nullptr, spill, SPILL_STRIDE, redo, 0u, d_stats);
 }
 
 template <bool COUNT>
@@ -319,14 +325,13 @@ void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill,
 {
     const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->trace_impl == 0) { TRT_LAUNCH_SHADOW(1, false, 0, 0); return; }
-    if (h->node_kind == 1) TRT_BY_IMPL(TRT_LAUNCH_SHADOW, 1);
-    else TRT_BY_IMPL(TRT_LAUNCH_SHADOW, 0);
+    if (h->node_kind == 1) TRT_BY_OCT_DEPTH(TRT_LAUNCH_SHADOW);
+    else TRT_BY_DEPTH(TRT_LAUNCH_SHADOW, 3, 0);
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;
     src.s0 = 0;
-    if (h->node_kind == 1) hipLaunchKernelGGL((k_trace_fix<true, false, 1>), dim3(1), b, 0, stream, h->sc, src, (f4*)nullptr, (const f4*)sq.sw, light_mat, Lacc, spill, SPILL_STRIDE, redo, any);
-    else hipLaunchKernelGGL((k_trace_fix<true, false, 0>), dim3(1), b, 0, stream, h->sc, src, (f4*)nullptr, (const f4*)sq.sw, light_mat, Lacc, spill, SPILL_STRIDE, redo, any);
+    hipLaunchKernelGGL((k_trace_fix<true, false, 0>), dim3(TRT_FIX_BLOCKS), b, 0, stream, h->sc, src, (f4*)nullptr, (const f4*)sq.sw, light_mat, Lacc, spill, SPILL_STRIDE, redo, any, d_stats);
 }
 
 }  // namespace
@@ -404,8 +409,8 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         for (uint32_t c : ch)
             if (!(c & TRT_LEAF_BIT) && c <= n) tiny = false;
     }
-    h->trace_impl = tiny ? 0 : (depth <= 8 ? 1 : 3);
-    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { const int v = std::atoi(e); if (v >= (tiny ? 0 : 1) && v <= 4) h->trace_impl = v; }
+    h->trace_impl = tiny ? 0 : 3;
+    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { if (std::atoi(e) == 3) h->trace_impl = 3; }  // tests: the per-lane driver on a tiny tree too
 
     {   // 48-B intersection records and 64-B shading records
         std::vector<TriIsect> isect(s->n_tris);
@@ -427,26 +432,31 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         const WideTree wide = greedy ? collapseBvhGreedy(s->nodes, s->n_nodes) : collapseBvh(s->nodes, s->n_nodes);
         h->sc.n_wnodes = (uint32_t)wide.nodes.size();
         h->depth = wide.stack_need + 1;
-        // 64-B compressed nodes + exact leaf boxes (nested trees only: every builder's is) are an OPTION, TRT_NODE_KIND=1: four
-        // loads per visit instead of seven, bit-identical results, but the 36 VALU instructions that rebuild the boxes cost
-        // more than the loads save on every scene but the 1 M-triangle soup (measured): the traversal kernels
-        // are bound by instruction issue, not by the texture-address rate.
-        bool want_c = false;
-        if (const char* e = std::getenv("TRT_NODE_KIND")) want_c = h->trace_impl != 0 && std::atoi(e) != 0;
-        CompressedTree comp;
-        if (want_c) comp = compressWide(wide, s->nodes, s->n_nodes, s->n_tris);
         h->sc.wnodes = nullptr;
-        h->sc.cnodes = nullptr;
         h->sc.leaf_box = nullptr;
         {   // the caller's box of every leaf: a hit in front of its own leaf's box does not count (leafEntry(), trt_path.h)
             const std::vector<f4> lb = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris);
             if (int e = upload(h.get(), lb.data(), lb.size(), &h->sc.leaf_box)) return e;
         }
-        if (comp.ok) {
-            h->node_kind = 1;
-            if (int e = upload(h.get(), comp.nodes.data(), comp.nodes.size(), &h->sc.cnodes)) return e;
-        } else {
-            if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
+        if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
+        // The 8-wide compressed nodes (trt_oct.h) for the persistent traversal kernels, when the tree qualifies (nested, finite, leaves
+        // of <= 3 triangles): TRT_NODE_KIND=0/1 in the environment forces either kind (A/B runs, tests).
+        h->sc.onodes = nullptr;
+        h->sc.tri_trav = nullptr;
+        bool want_oct = h->trace_impl != 0 && TRT_DEFAULT_NODE_KIND == 1;
+        if (const char* e = std::getenv("TRT_NODE_KIND")) want_oct = h->trace_impl != 0 && std::atoi(e) == 1;
+        if (want_oct) {
+            std::vector<TriIsect> isect(s->n_tris);
+            for (uint32_t i = 0; i < s->n_tris; ++i) isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, s->tri_mat[i], s->materials[s->tri_mat[i]].is_emissive != 0);
+            const OctTree oct = buildOct(s->nodes, s->n_nodes, s->n_tris, isect.data());
+            if (oct.ok) {
+                h->node_kind = 1;
+                h->oct_levels = oct.levels;
+                h->sc.n_onodes = (uint32_t)oct.nodes.size();
+                if (int e = upload(h.get(), oct.nodes.data(), oct.nodes.size(), &h->sc.onodes)) return e;
+                if (int e = upload(h.get(), oct.tri_trav.data(), oct.tri_trav.size(), &h->sc.tri_trav)) return e;
+            }
+            if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: oct tree %s (%s): %zu nodes, %u levels\n", oct.ok ? "built" : "not built", oct.why, oct.nodes.size(), oct.levels);
         }
         if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: %zu wide nodes, node kind %d, stack need %u\n", wide.nodes.size(), h->node_kind, wide.stack_need);
     }
@@ -493,6 +503,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     h->sc.n_nodes = s->n_nodes;
     h->sc.n_lights = s->n_lights;
     h->sc.light0_area = s->n_lights ? s->lights[0].area : 0.0f;
+    h->sc.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
     h->sc.cam = s->camera;
     for (uint32_t i = 0; i < s->n_lights; ++i) h->light_mats.push_back((uint32_t)s->lights[i].mat);
     {   // which small tables k_shade copies into LDS: in this order while they fit (uploads are padded to 16 B)
@@ -535,7 +546,8 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     }
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
-    const uint32_t spill_levels = h->depth > (uint32_t)TRT_LDS_STACK_MAX ? h->depth - TRT_LDS_STACK_MAX + 1 : 1;
+    uint32_t spill_levels = h->depth > (uint32_t)TRT_LDS_STACK_MAX ? h->depth - TRT_LDS_STACK_MAX + 1 : 1;
+    if (h->node_kind == 1 && h->oct_levels > OCT_LDS_DEEP) spill_levels = std::max(spill_levels, 2u * (h->oct_levels - OCT_LDS_DEEP + 1));  // two words per level
     h->spill_words_per_slot = (size_t)spill_levels * SPILL_STRIDE;
     if (int e = h->spill.ensure(h->spill_words_per_slot * 2 * sizeof(uint32_t))) return e;  // one area per concurrent pass
     for (hipStream_t& st : h->slot_streams) HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -650,7 +662,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     int32_t* d_rows = (int32_t*)sb;
     DeviceStats* d_stats = (DeviceStats*)(sb + rows_bytes + counts_bytes * N_SLOTS);
     static_assert(sizeof(DeviceStats) <= 128, "the redo counters of the pass slots live behind the statistics");
-    uint32_t* d_redo = (uint32_t*)(sb + rows_bytes + counts_bytes * N_SLOTS + 128);  // one counter per slot
+    uint32_t* d_redo = (uint32_t*)(sb + rows_bytes + counts_bytes * N_SLOTS + 128);  // per slot: length of the redo list, blocks of k_trace_fix that are through
     double* d_acc = (double*)(sb + rows_bytes + counts_bytes * N_SLOTS + stats_bytes);
 
     PassSlot slots[N_SLOTS];
@@ -665,7 +677,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         for (uint32_t l = 0; l < (uint32_t)TRT_MAX_LIGHTS; ++l) S.SQ[l] = ShadowQueue{nullptr, nullptr, nullptr};
         for (uint32_t l = 0; l < nl; ++l) { S.SQ[l].sa = take(); S.SQ[l].sb = take(); S.SQ[l].sw = take(); }
         S.redo.idx = (uint32_t*)base;  // N indices behind the queues
-        S.redo.count = d_redo + k;
+        S.redo.count = d_redo + 2 * k;
         S.d_counts = (uint32_t*)(sb + rows_bytes + counts_bytes * (size_t)k);
         S.host_counts = h->pinned_counts + (size_t)k * (2 * COUNT_ROW + 16);
         S.seq = h->slot_seq[k];
@@ -851,13 +863,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
             TA.uniform = h->trace_impl == 0 ? 1u : 0u;
             TA.stats = d_stats;
             tm.begin(TRT_K_TAIL, S.stream);
-            if (h->node_kind == 1) {
-                if (count) hipLaunchKernelGGL((k_tail<true, 1>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
-                else hipLaunchKernelGGL((k_tail<false, 1>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
-            } else {
-                if (count) hipLaunchKernelGGL((k_tail<true, 0>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
-                else hipLaunchKernelGGL((k_tail<false, 0>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
-            }
+            if (count) hipLaunchKernelGGL((k_tail<true, 0>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
+            else hipLaunchKernelGGL((k_tail<false, 0>), dim3(tailGrid(S.n_active)), dim3(TRT_TRACE_BLOCK), 0, S.stream, h->sc, TA);
             tm.end(S.stream);
             st.launches[TRT_K_TAIL]++;
             S.n_active = 0;
@@ -920,9 +927,10 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     st.rays_indirect += ds.tail_rays_indirect;
     for (int i = 0; i < 2; ++i) { st.inner_visits[i] = ds.inner_visits[i]; st.tri_tests[i] = ds.tri_tests[i]; }
     st.max_bounces = ds.max_depth_hit;
+    st.redo_rays = ds.redo_rays;
     st.passes = n_chunks;
     st.rows_rendered = rows.size();
-    st.inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(CNode) : (uint32_t)sizeof(WideNode));
+    st.inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(OctNode) : (uint32_t)sizeof(WideNode));
     if (stats_out) *stats_out = st;
     return TRT_OK;
 }
@@ -1026,7 +1034,8 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
         stats_out->wave_steps[1] = ds.wave_leaf_steps;
         stats_out->kernel_ms[TRT_K_TRACE_CLOSEST] = ms;
         stats_out->launches[TRT_K_TRACE_CLOSEST] = 1;
-        stats_out->inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(CNode) : (uint32_t)sizeof(WideNode));
+        stats_out->inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(OctNode) : (uint32_t)sizeof(WideNode));
+        stats_out->redo_rays = ds.redo_rays;
     }
     return TRT_OK;
 }
@@ -1077,17 +1086,69 @@ __global__ __launch_bounds__(256) void k_uninterleave(const float* __restrict__ 
 }
 }  // namespace
 
+// One host thread per device for the life of the group: it binds its device once and renders its stripes whenever the
+// group posts a job (trt_group_render used to create and join n threads per call).
+struct GroupWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t posted = 0, finished = 0;  // job sequence numbers
+    bool quit = false;
+    // the job
+    trt_handle* h = nullptr;
+    trt_params p{};
+    float* out = nullptr;
+    hipStream_t stream = nullptr;
+    bool skip = false;  // more devices than stripes: nothing to render
+    // its result
+    int rc = TRT_OK;
+    std::string msg;
+    trt_stats st{};
+};
+
 struct trt_group {
     std::vector<trt_handle*> handles;
     std::vector<int> devices;
-    bool distinct = false;       // every entry another device: RCCL gathers; else device copies (one-GPU rehearsal)
+    bool use_rccl = false;       // every entry another device (or the one-device test switch): RCCL gathers; else device copies (one-GPU rehearsal)
     Rccl rccl;
     std::vector<void*> comms;
     std::vector<hipStream_t> streams;
     std::vector<DevBuf> stripe;  // per rank: its packed stripes, padded to the largest rank's row count
     DevBuf gathered, image;      // on devices[0]
+    std::vector<std::unique_ptr<GroupWorker>> workers;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // on devices[0]: around gather + un-interleave
+    void startWorkers()
+    {
+        for (size_t k = 0; k < handles.size(); ++k) {
+            workers.emplace_back(new GroupWorker);
+            GroupWorker* w = workers.back().get();
+            const int dev = devices[k];
+            w->th = std::thread([w, dev]() {
+                (void)hipSetDevice(dev);
+                std::unique_lock<std::mutex> lk(w->mu);
+                for (;;) {
+                    w->cv.wait(lk, [w]() { return w->quit || w->posted != w->finished; });
+                    if (w->quit) return;
+                    lk.unlock();
+                    if (w->skip) { std::memset(&w->st, 0, sizeof(w->st)); w->rc = TRT_OK; }
+                    else {
+                        w->rc = trt_render_device(w->h, &w->p, w->out, w->stream, &w->st);
+                        if (w->rc) w->msg = trt_last_error();  // thread-local in the worker: carried over by hand
+                    }
+                    lk.lock();
+                    w->finished = w->posted;
+                    w->cv.notify_all();
+                }
+            });
+        }
+    }
     ~trt_group()
     {
+        for (auto& w : workers) {
+            { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
         for (size_t k = 0; k < handles.size(); ++k) {
             (void)hipSetDevice(devices[k]);
             if (k < stripe.size()) stripe[k].release();
@@ -1096,6 +1157,8 @@ struct trt_group {
             trt_destroy(handles[k]);
         }
         if (!devices.empty()) (void)hipSetDevice(devices[0]);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
         gathered.release();
         image.release();
         if (rccl.lib) dlclose(rccl.lib);
@@ -1113,13 +1176,15 @@ int trt_group_create(const trt_scene* scene, int n_devices, const int* devices, 
     if (!scene || !devices || !out || n_devices < 1 || n_devices > 64) return fail(TRT_EINVAL, "trt_group_create: bad argument");
     *out = nullptr;
     std::unique_ptr<trt_group> g(new trt_group);
-    g->distinct = true;
+    bool distinct = true;
     for (int a = 0; a < n_devices; ++a)
         for (int b = a + 1; b < n_devices; ++b)
-            if (devices[a] == devices[b]) g->distinct = false;
+            if (devices[a] == devices[b]) distinct = false;
+    const char* force = std::getenv("TRT_GROUP_FORCE_RCCL");  // test switch: a group of one device takes the RCCL route too
+    g->use_rccl = distinct && (n_devices > 1 || (force && std::atoi(force) != 0));
     for (int k = 0; k < n_devices; ++k) {
         trt_handle* h = nullptr;
-        if (int e = trt_create(scene, devices[k], &h)) return e;  // message already set
+        if (int e = trt_create(scene, devices[k], &h)) return e;  // message already set (TRT_ENODEV for an ordinal the node does not have)
         g->handles.push_back(h);
         g->devices.push_back(devices[k]);
     }
@@ -1129,20 +1194,24 @@ int trt_group_create(const trt_scene* scene, int n_devices, const int* devices, 
         HIPC(hipSetDevice(devices[k]));
         HIPC(hipStreamCreateWithFlags(&g->streams[k], hipStreamNonBlocking));
     }
-    if (n_devices > 1 && g->distinct) {
+    HIPC(hipSetDevice(devices[0]));
+    HIPC(hipEventCreate(&g->ev0));
+    HIPC(hipEventCreate(&g->ev1));
+    if (g->use_rccl) {
         std::string err;
         if (!g->rccl.load(err)) return fail(TRT_EHIP, err);
         g->comms.assign(n_devices, nullptr);
         const int rc = g->rccl.CommInitAll(g->comms.data(), n_devices, devices);
         if (rc != 0) return fail(TRT_EHIP, std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(rc));
     }
+    g->startWorkers();
     *out = g.release();
     return TRT_OK;
 }
 
-int trt_group_render(trt_group* g, const trt_params* p_in, float* out_host, trt_stats* stats_out, double* gather_ms_out)
+int trt_group_render_device(trt_group* g, const trt_params* p_in, float* out_dev0, trt_stats* stats_out, double* gather_ms_out)
 {
-    if (!g || !p_in || !out_host) return fail(TRT_EINVAL, "trt_group_render: null argument");
+    if (!g || !p_in || !out_dev0) return fail(TRT_EINVAL, "trt_group_render_device: null argument");
     const int n = (int)g->handles.size();
     trt_params p = *p_in;
     if (p.row_block <= 0) p.row_block = 8;
@@ -1150,9 +1219,8 @@ int trt_group_render(trt_group* g, const trt_params* p_in, float* out_host, trt_
     p.row_rem = 0;
     if (int e = checkParams(g->handles[0], &p)) return e;
     const uint32_t tile_rows = (uint32_t)(p.y1 - p.y0), tw = (uint32_t)(p.x1 - p.x0), row_floats = tw * 3u;
-    // The interleave of trt_params counts stripes from image row 0, the group from the tile's first row: the tile is
-    // rendered as its own interleave domain by shifting nothing — rows are selected on absolute y, so the packed index
-    // used by k_uninterleave must be computed on absolute y as well.  Keep it simple: require y0 to be stripe aligned.
+    // Rows are selected on absolute y (stripes are counted from image row 0), and k_uninterleave computes the packed index the
+    // same way only if the tile starts on a stripe boundary of rank 0: require that.
     if (p.y0 % (p.row_block * n) != 0) return fail(TRT_EINVAL, "trt_group_render: y0 must be a multiple of row_block * group size");
     uint32_t pad_rows = 0;
     std::vector<uint32_t> rows_of(n);
@@ -1169,64 +1237,69 @@ int trt_group_render(trt_group* g, const trt_params* p_in, float* out_host, trt_
     }
     HIPC(hipSetDevice(g->devices[0]));
     if (int e = g->gathered.ensure(stripe_bytes * (size_t)n)) return e;
-    if (int e = g->image.ensure((size_t)tile_rows * row_floats * sizeof(float))) return e;
 
-    // ---- every device renders its stripes on its own host thread
-    std::vector<int> rcs(n, TRT_OK);
-    std::vector<std::string> msgs(n);
-    std::vector<trt_stats> sts(n);
-    std::vector<std::thread> threads;
+    // ---- every device renders its stripes on its own (resident) host thread
     for (int k = 0; k < n; ++k) {
-        threads.emplace_back([&, k]() {
-            trt_params pk = p;
-            pk.row_rem = k;
-            if (rows_of[k] == 0) { std::memset(&sts[k], 0, sizeof(trt_stats)); return; }  // more devices than stripes
-            rcs[k] = trt_render_device(g->handles[k], &pk, (float*)g->stripe[k].p, g->streams[k], &sts[k]);
-            if (rcs[k]) msgs[k] = trt_last_error();  // thread-local in the worker: carried over by hand
-        });
+        GroupWorker* w = g->workers[k].get();
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->h = g->handles[k];
+        w->p = p;
+        w->p.row_rem = k;
+        w->out = (float*)g->stripe[k].p;
+        w->stream = g->streams[k];
+        w->skip = rows_of[k] == 0;
+        w->posted++;
+        w->cv.notify_all();
     }
-    for (auto& t : threads) t.join();
+    for (int k = 0; k < n; ++k) {
+        GroupWorker* w = g->workers[k].get();
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [w]() { return w->posted == w->finished; });
+    }
     for (int k = 0; k < n; ++k)
-        if (rcs[k]) return fail(rcs[k], "device " + std::to_string(g->devices[k]) + ": " + msgs[k]);
+        if (g->workers[k]->rc) return fail(g->workers[k]->rc, "device " + std::to_string(g->devices[k]) + ": " + g->workers[k]->msg);
 
-    // ---- ONE gather to devices[0], then un-interleave there
+    // ---- ONE gather to devices[0], then un-interleave there (every worker's stream is idle: trt_render_device synchronises it)
     HIPC(hipSetDevice(g->devices[0]));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    struct Ev { hipEvent_t& a; hipEvent_t& b; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev{e0, e1};
-    HIPC(hipEventCreate(&e0));
-    HIPC(hipEventCreate(&e1));
-    HIPC(hipEventRecord(e0, g->streams[0]));
+    HIPC(hipEventRecord(g->ev0, g->streams[0]));
     const size_t count = (size_t)pad_rows * row_floats;
-    if (n > 1 && g->distinct) {
+    if (g->use_rccl) {
+        // Between GroupStart and GroupEnd nothing returns: an error is remembered, the group is closed, then it is reported.
         int rc = g->rccl.GroupStart();
-        for (int k = 0; k < n && rc == 0; ++k) {
-            HIPC(hipSetDevice(g->devices[k]));
-            rc = g->rccl.Gather(g->stripe[k].p, k == 0 ? g->gathered.p : nullptr, count, NCCL_FLOAT32, 0, g->comms[k], g->streams[k]);
+        hipError_t herr = hipSuccess;
+        if (rc == 0) {
+            for (int k = 0; k < n && rc == 0 && herr == hipSuccess; ++k) {
+                herr = hipSetDevice(g->devices[k]);
+                if (herr == hipSuccess) rc = g->rccl.Gather(g->stripe[k].p, k == 0 ? g->gathered.p : nullptr, count, NCCL_FLOAT32, 0, g->comms[k], g->streams[k]);
+            }
+            const int rc_end = g->rccl.GroupEnd();
+            if (rc == 0) rc = rc_end;
         }
-        const int rc_end = g->rccl.GroupEnd();
-        if (rc == 0) rc = rc_end;
+        (void)hipSetDevice(g->devices[0]);
+        if (herr != hipSuccess) return fail(TRT_EHIP, std::string("hipSetDevice inside the gather: ") + hipGetErrorString(herr));
         if (rc != 0) return fail(TRT_EHIP, std::string("ncclGather: ") + g->rccl.GetErrorString(rc));
-        for (int k = 1; k < n; ++k) { HIPC(hipSetDevice(g->devices[k])); HIPC(hipStreamSynchronize(g->streams[k])); }
-        HIPC(hipSetDevice(g->devices[0]));
     } else {
         for (int k = 0; k < n; ++k)
             HIPC(hipMemcpyAsync((char*)g->gathered.p + stripe_bytes * (size_t)k, g->stripe[k].p, stripe_bytes, hipMemcpyDeviceToDevice, g->streams[0]));
     }
+    // the root's share of the gather runs on streams[0]: the kernel below is ordered behind it by the stream
     const uint64_t total = (uint64_t)tile_rows * row_floats;
     hipLaunchKernelGGL(k_uninterleave, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536ull)), dim3(256), 0, g->streams[0], (const float*)g->gathered.p,
-                       (float*)g->image.p, tile_rows, row_floats, (uint32_t)p.row_block, (uint32_t)n, pad_rows);
-    HIPC(hipEventRecord(e1, g->streams[0]));
-    HIPC(hipMemcpyAsync(out_host, g->image.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, g->streams[0]));
+                       out_dev0, tile_rows, row_floats, (uint32_t)p.row_block, (uint32_t)n, pad_rows);
+    HIPC(hipEventRecord(g->ev1, g->streams[0]));
     HIPC(hipStreamSynchronize(g->streams[0]));
     HIPC(hipGetLastError());
+    if (g->use_rccl)  // the senders' stripes may be overwritten by the next render only after their part of the gather has left
+        for (int k = 1; k < n; ++k) { HIPC(hipSetDevice(g->devices[k])); HIPC(hipStreamSynchronize(g->streams[k])); }
+    HIPC(hipSetDevice(g->devices[0]));
     float gms = 0.f;
-    HIPC(hipEventElapsedTime(&gms, e0, e1));
+    HIPC(hipEventElapsedTime(&gms, g->ev0, g->ev1));
     if (gather_ms_out) *gather_ms_out = gms;
     if (stats_out) {
         trt_stats t;
         std::memset(&t, 0, sizeof(t));
         for (int k = 0; k < n; ++k) {
-            const trt_stats& s = sts[k];
+            const trt_stats& s = g->workers[k]->st;
             t.rays_camera += s.rays_camera; t.rays_shadow += s.rays_shadow; t.rays_indirect += s.rays_indirect; t.shaded_hits += s.shaded_hits;
             for (int i = 0; i < 2; ++i) { t.inner_visits[i] += s.inner_visits[i]; t.tri_tests[i] += s.tri_tests[i]; t.wave_steps[i] += s.wave_steps[i]; }
             for (int i = 0; i < TRT_MAX_KERNELS; ++i) { t.launches[i] += s.launches[i]; t.kernel_ms[i] += s.kernel_ms[i]; }
@@ -1235,9 +1308,23 @@ int trt_group_render(trt_group* g, const trt_params* p_in, float* out_host, trt_
             t.max_bounces = std::max(t.max_bounces, s.max_bounces);
             t.rows_rendered += s.rows_rendered;
             t.inner_node_bytes = std::max(t.inner_node_bytes, s.inner_node_bytes);
+            t.redo_rays += s.redo_rays;
         }
         *stats_out = t;
     }
+    return TRT_OK;
+}
+
+int trt_group_render(trt_group* g, const trt_params* p_in, float* out_host, trt_stats* stats_out, double* gather_ms_out)
+{
+    if (!g || !p_in || !out_host) return fail(TRT_EINVAL, "trt_group_render: null argument");
+    if (p_in->x1 <= p_in->x0 || p_in->y1 <= p_in->y0) return fail(TRT_EINVAL, "tile rectangle outside the image or empty");
+    const size_t bytes = (size_t)(p_in->y1 - p_in->y0) * (size_t)(p_in->x1 - p_in->x0) * 3 * sizeof(float);
+    HIPC(hipSetDevice(g->devices[0]));
+    if (int e = g->image.ensure(bytes)) return e;
+    if (int e = trt_group_render_device(g, p_in, (float*)g->image.p, stats_out, gather_ms_out)) return e;
+    HIPC(hipSetDevice(g->devices[0]));
+    HIPC(hipMemcpy(out_host, g->image.p, bytes, hipMemcpyDeviceToHost));
     return TRT_OK;
 }
 

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "trt_path.h"
+#include "trt_oct.h"
 
 namespace trtd {
 
@@ -37,10 +38,6 @@ namespace trtd {
 #define TRT_TRACE_BOUNDS __launch_bounds__(256)
 #endif
 constexpr int TRT_TRACE_BLOCK = 256;
-// TRT_SHADOW_UNORDERED: the persistent drivers take the hit children of a node in slot order for shadow rays (no sort)
-#ifndef TRT_SHADOW_UNORDERED
-#define TRT_SHADOW_UNORDERED 0
-#endif
 #ifndef TRT_LDS_STACK_MAX_LEVELS
 #define TRT_LDS_STACK_MAX_LEVELS 16
 #endif
@@ -80,7 +77,7 @@ struct DeviceStats {
     unsigned long long tail_rays_shadow, tail_rays_indirect;  // rays traced inside k_tail
     unsigned long long wave_inner_steps, wave_leaf_steps;     // wave-level iterations of the two traversal phases (COUNT)
     unsigned int max_depth_hit;
-    unsigned int pad;
+    unsigned int redo_rays;  // rays whose result failed the leaf-box check and went through k_trace_fix
 };
 
 // DEPTH levels live in LDS ([level][lane]: conflict-free, one ds_read/ds_write per access).  With
@@ -103,6 +100,31 @@ struct LdsStack {
         asm volatile("" : "+v"(v));  // keep this a ds_read: without it the two address spaces merge into a flat load
         if (sp >= DEPTH) v = spill[(size_t)(sp - DEPTH) * spill_stride];
         return v;
+    }
+};
+
+// The same for the 8-byte groups of the oct traversal (trt_oct.h): level `sp` lives at words (2 sp, 2 sp + 1) x [lane].
+template <int DEPTH, bool SPILL>
+struct OctLdsStack {
+    uint32_t* lds;    // &smem[threadIdx.x]
+    uint32_t* spill;  // &spill[global thread id]
+    uint32_t spill_stride;
+    __device__ void push(int sp, OctGroup g)
+    {
+        if (!SPILL || sp < DEPTH) { lds[(2 * sp) * TRT_TRACE_BLOCK] = g.x; lds[(2 * sp + 1) * TRT_TRACE_BLOCK] = g.y; }
+        else { spill[(size_t)(2 * (sp - DEPTH)) * spill_stride] = g.x; spill[(size_t)(2 * (sp - DEPTH) + 1) * spill_stride] = g.y; }
+    }
+    __device__ OctGroup pop(int sp) const
+    {
+        OctGroup g;
+        const int l = (!SPILL || sp < DEPTH) ? sp : DEPTH - 1;
+        g.x = lds[(2 * l) * TRT_TRACE_BLOCK];
+        g.y = lds[(2 * l + 1) * TRT_TRACE_BLOCK];
+        if (SPILL) {
+            asm volatile("" : "+v"(g.x), "+v"(g.y));  // keep these ds_reads (see LdsStack::pop)
+            if (sp >= DEPTH) { g.x = spill[(size_t)(2 * (sp - DEPTH)) * spill_stride]; g.y = spill[(size_t)(2 * (sp - DEPTH) + 1) * spill_stride]; }
+        }
+        return g;
     }
 };
 
@@ -135,19 +157,17 @@ __device__ inline unsigned long long waveSum(unsigned long long v)
 // visiting order, the culling rule and the tie rules are exactly
 // traceClosest()'s (trt_path.h), whichever driver below runs it.
 //
-// IMPL selects the wave-level driver (run time: trt_create picks it from the BVH depth, TRT_TRACE_IMPL
-// in the environment overrides):
+// IMPL selects the wave-level driver (trt_create picks it per scene):
 //   0  wave-uniform walk of a tiny tree (<= 32 inner nodes, <= 64 triangles): scalar loads, no stack
-//   1  static: lane i takes rays i, i+stride, ...; a wave waits for its longest ray
-//   2  persistent wave, while-while: each wave owns a contiguous queue slice and refills finished
-//      lanes from it (__ballot of free lanes, rank = popcount of the lower free lanes); inner-node
-//      steps run until no lane holds an inner node, then all pending leaves are intersected
-//   3  persistent wave with a per-step scheduler: each iteration runs the step kind (inner node /
-//      one triangle) that more lanes are waiting for
-// sc.refill_min (impl 2, 3): finished lanes are written back and refilled in batches of at least this many lanes:
+//   3  persistent wave with a per-step scheduler: each wave owns a contiguous queue slice and refills finished lanes from
+//      it (__ballot of free lanes, rank = popcount of the lower free lanes); each iteration runs the step kind (inner
+//      node / one triangle) that more lanes are waiting for
+// (Round 2 also carried a static driver, a while-while driver and a scheduler with a postponed leaf; they lost on every
+// shipped scene — DESIGN.md §4.1 has the matrix — and are gone.)
+// sc.refill_min: finished lanes are written back and refilled in batches of at least this many lanes:
 // ray set-up (three IEEE reciprocals) and result write-back (the winner's barycentrics) then run at decent lane
-// utilisation.  Chosen per scene in trt_create (TRT_REFILL_MIN in the environment overrides): short traversals
-// want large batches (staircase 454 -> 434 ms/step at 48 instead of 16), deep trees smaller ones (blob, soup: 32).
+// utilisation.  Chosen per scene in trt_create: short traversals want large batches (staircase 454 -> 434 ms/step at 48
+// instead of 16), deep trees smaller ones (blob, soup: 32).
 
 // Where a traversal kernel takes ray `i` from: the queue in HBM, or (PRIMARY) the camera-ray generator.
 struct RaySource {
@@ -208,7 +228,9 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
 // that result in ONE memory round trip: the leaf's box is requested together with what the store needs (the winner's record, or the
 // shadow ray's weight and the sample's radiance), and only then is the entry distance formed.  Returns true when the result fails
 // the check: nothing is stored then and the caller puts the ray on the redo list.
-template <bool SHADOW>
+// OCT: the result of a traversal of the quantised 8-wide nodes (trt_oct.h) counts only if the ray also passes the reference's test of the
+// exact box of the triangle's leaf.
+template <bool SHADOW, bool OCT = false>
 __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 inv, float best_t, int32_t best_tri, uint32_t best_flags, uint32_t idx, uint32_t pid,
                                              f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, bool any)
 {
@@ -217,8 +239,8 @@ __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 
     if (!SHADOW) {
         const TriIsect T = sc.tri_isect[tri];
         float e;
-        (void)boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
-        if (best_tri >= 0 && best_t < e) return true;
+        const bool pass = boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
+        if (best_tri >= 0 && ((OCT && !pass) || best_t < trt_leaf_floor(e, sc.leaf_alpha))) return true;
         float u = 0.f, v = 0.f;
         if (best_tri >= 0) {
             float t, un, vn, det;
@@ -230,8 +252,8 @@ __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 
         f4 w = mk4(0, 0, 0, 0), L = w;
         if (vis) { w = sw[idx]; L = Lacc[pid]; }
         float e;
-        (void)boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
-        if (best_tri >= 0 && best_t < e) return true;
+        const bool pass = boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
+        if (best_tri >= 0 && ((OCT && !pass) || best_t < trt_leaf_floor(e, sc.leaf_alpha))) return true;
         if (vis) {
             L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
             Lacc[pid] = L;
@@ -274,7 +296,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
             if (s < n_pend) {
                 const f4 e = my_pend[s * STRIDE];
                 const float t = e.x / e.y;
-                if (!(t < TRT_T_MIN) && !(t < e.w)) {  // bvh.cpp:189; and not in front of the box of its leaf (leafEntry(), trt_path.h)
+                if (!(t < TRT_T_MIN) && !(t < e.w)) {  // bvh.cpp:189; and not in front of the box of its leaf (leafFloor(), trt_path.h)
                     const uint32_t pk = f2u(e.z);  // triangle index | first triangle of its leaf << 8 | triangles in the leaf << 16 (<= 64 triangles here)
                     const int32_t j = (int32_t)(pk & 0xFFu);
                     const uint32_t fl = f2u(sc.tri_isect[j].c.z);
@@ -300,6 +322,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
         float e0 = 0.0f, e1 = 0.0f;
         const bool h0 = at && boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
         const bool h1 = at && boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
+        const float f0 = trt_leaf_floor(e0, sc.leaf_alpha), f1 = trt_leaf_floor(e1, sc.leaf_alpha);  // used only where the child is a leaf
         const uint32_t child[2] = {f2u(q3.x), f2u(q3.y)};
         const bool hc[2] = {h0, h1};
 #pragma unroll
@@ -322,7 +345,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
                 // a full queue among the candidates: empty all of them first (votes on the single compares: their own lane masks)
                 if ((ballotb(ok_det) & ballotb(ok_in) & m_hc & ballotb(n_pend == (uint32_t)TRT_PEND_SLOTS)) != 0ull) flush();
                 if (cand) {
-                    my_pend[n_pend * STRIDE] = mk4(tn, det, u2f((first + k) | (first << 8) | (count << 16)), c == 0 ? e0 : e1);  // + the entry of the leaf's box
+                    my_pend[n_pend * STRIDE] = mk4(tn, det, u2f((first + k) | (first << 8) | (count << 16)), c == 0 ? f0 : f1);  // + the floor of the leaf's box (leaf-box rule)
                     n_pend++;
                 }
             }
@@ -363,44 +386,6 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
     }
 }
 
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY, int NK>
-__device__ __forceinline__ void traceQueueStatic(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
-                                           const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
-{
-    LdsStack<DEPTH, SPILL> stk;
-    stk.lds = smem + threadIdx.x;
-    stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
-    stk.spill_stride = spill_stride;
-    uint32_t n_inner = 0, n_tri = 0;
-    const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
-    const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
-    for (uint32_t i = lb * TRT_TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
-        f4 a, b;
-        fetchRay<PRIMARY>(sc, src, i, a, b);
-        const bool any = SHADOW && any_flag;
-        const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
-        const Hit h = traceClosestPass<LdsStack<DEPTH, SPILL>, COUNT, NK, false>(sc, o, d, stk, n_inner, n_tri, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
-        if (hitInFrontOfItsLeaf(sc, h.t, h.tri, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) {
-            redo.idx[atomicAdd(redo.count, 1u)] = i;  // k_trace_fix traces it again
-        } else if (!SHADOW) {
-            hit[i] = mk4(h.t, u2f((uint32_t)h.tri), h.u, h.v);
-        } else if (any ? h.tri < 0 : (h.tri >= 0 && (h.flags >> 8) == light_mat)) {
-            const f4 w = sw[i];
-            const uint32_t pid = f2u(b.z);
-            f4 L = Lacc[pid];
-            L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
-            Lacc[pid] = L;
-        }
-    }
-    if (COUNT) {
-        const unsigned long long si = waveSum(n_inner), st = waveSum(n_tri);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats->inner_visits[SHADOW ? 1 : 0], si);
-            atomicAdd(&stats->tri_tests[SHADOW ? 1 : 0], st);
-        }
-    }
-}
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
@@ -429,7 +414,6 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
     uint32_t best_flags = 0;
     // IMPL 3: fold state of the leaf the lane is in (interactBVHNode's local `res`, bvh.cpp:213)
     uint32_t lk = 0;  // next triangle of the leaf, relative to its first
-    uint32_t post = TRT_REF_IDLE;  // IMPL 4: a leaf parked for a later leaf step (TRT_REF_IDLE = none)
     float lt = TRT_INF;
     int32_t li = -1;
     uint32_t lflags = 0;
@@ -463,7 +447,6 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                     sp = 0;
                     cur = 0u;  // nodes[0] is always an inner node
                     lk = 0; lt = TRT_INF; li = -1;
-                    post = TRT_REF_IDLE;
                 }
                 const uint32_t taken = (uint32_t)__popcll(m_free);
                 next = (end - next) < taken ? end : next + taken;
@@ -471,118 +454,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             if (ballotb(cur < TRT_REF_DONE) == 0ull) break;  // nothing left in the slice
         }
 
-        if constexpr (IMPL == 2) {
-        // ---- inner-node phase: until no lane of the wave holds an inner node
-        for (;;) {
-            const bool is_inner = !(cur & TRT_LEAF_BIT);
-            const unsigned long long m = ballotb(is_inner);
-            if (m == 0ull) break;
-            if (is_inner) {
-                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_inner++; }
-                if (!innerStep<NK, LdsStack<DEPTH, SPILL>, !(SHADOW && TRT_SHADOW_UNORDERED)>(sc, cur, sp, stk, o, inv, best_t)) {
-                    if (sp != 0) cur = stk.pop(--sp);
-                    else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }  // nothing in front of the hint: search again without it
-                    else cur = TRT_REF_DONE;
-                }
-            }
-        }
-        // ---- leaf phase: every working lane now holds a leaf
-        for (;;) {
-            const bool is_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
-            const unsigned long long m = ballotb(is_leaf);
-            if (m == 0ull) break;
-            if (is_leaf) {
-                const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
-                lt = TRT_INF;
-                li = -1;
-                lflags = 0u;
-                for (uint32_t k = 0; k < count; ++k) {  // interactBVHNode (bvh.cpp:211-229): index order
-                    const uint32_t i = first + k;
-                    const TriIsect T = sc.tri_isect[i];
-                    if (COUNT) pr.n_tri++;
-                    float t, un, vn, det;
-                    if (triTest(T, o, d, t, un, vn, det)) {
-                        const uint32_t fl = f2u(T.c.z);
-                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lflags = fl; }
-                    }
-                }
-                if (li >= 0) {
-                    bool take = lt < best_t;
-                    if (lt == best_t && best_tri >= 0) {  // equal distance across leaves (bvh.cpp:168-172, order independent form)
-                        const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
-                        take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
-                    }
-                    if (NK == 1 && take) take = leafBoxPasses(sc, first, o, inv);  // compressed nodes: the leaf's exact box decides
-                    if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
-                }
-                if (any && best_tri >= 0) cur = TRT_REF_DONE;
-                else if (sp != 0) cur = stk.pop(--sp);
-                else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }
-                else cur = TRT_REF_DONE;
-            }
-            if (COUNT && lane == (uint32_t)__ffsll((long long)m) - 1u) pr.wave_tri++;
-        }
-        } else if constexpr (IMPL == 4) {
-        // ---- scheduler with a postponed leaf (speculative traversal): a lane that arrives at a leaf parks it in `post`
-        // and goes on with the next node from its stack, so node steps keep more lanes busy; leaf steps then serve every
-        // lane that has a leaf pending — the parked one first, then the one it stands on.  The price is a later best_t
-        // (a few nodes more are visited); the result cannot change: which leaves and nodes are looked at, and in what
-        // order, never enters the hit (traceClosest's tie rules are order independent, culling is by strict distance).
-        if ((cur & TRT_LEAF_BIT) && cur < TRT_REF_DONE && post == TRT_REF_IDLE && sp != 0) { post = cur; cur = stk.pop(--sp); }
-        const bool is_inner = !(cur & TRT_LEAF_BIT);
-        const bool cur_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
-        const bool leaf_work = cur_leaf || post != TRT_REF_IDLE;
-        const unsigned long long m_in = ballotb(is_inner), m_blk = ballotb(cur_leaf), m_lw = ballotb(leaf_work);
-        bool adv = false;
-        if (sc.sched_in_w * (uint32_t)__popcll(m_in) >= sc.sched_lf_w * (uint32_t)__popcll(m_blk)) {
-            if (is_inner) {
-                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
-                if (!innerStep<NK, LdsStack<DEPTH, SPILL>, !(SHADOW && TRT_SHADOW_UNORDERED)>(sc, cur, sp, stk, o, inv, best_t)) adv = true;
-            }
-        } else {
-            if (leaf_work) {
-                const bool from_post = post != TRT_REF_IDLE;
-                const uint32_t lref = from_post ? post : cur;
-                const uint32_t first = TRT_LEAF_FIRST(lref), count = TRT_LEAF_COUNT(lref);
-                if (lk < count) {
-                    const uint32_t i = first + lk;
-                    const TriIsect T = sc.tri_isect[i];
-                    if (COUNT) { pr.n_tri++; if (lane == (uint32_t)__ffsll((long long)m_lw) - 1u) pr.wave_tri++; }
-                    float t, un, vn, det;
-                    if (triTest(T, o, d, t, un, vn, det)) {
-                        const uint32_t fl = f2u(T.c.z);
-                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lflags = fl; }
-                    }
-                    lk++;
-                }
-                if (lk >= count) {  // leaf done: merge its winner
-                    if (li >= 0) {
-                        bool take = lt < best_t;
-                        if (lt == best_t && best_tri >= 0) {
-                            const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
-                            take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
-                        }
-                        if (NK == 1 && take) take = leafBoxPasses(sc, first, o, inv);
-                        if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
-                    }
-                    lk = 0; lt = TRT_INF; li = -1;
-                    if (from_post) {
-                        post = TRT_REF_IDLE;  // the lane goes on with the node it stands on
-                        if (any && best_tri >= 0) { cur = TRT_REF_DONE; }
-                    } else {
-                        adv = true;
-                    }
-                }
-            }
-        }
-        if (adv) {  // done with the node the lane stands on (post is empty here, or the node was an inner one)
-            if (any && best_tri >= 0) { cur = TRT_REF_DONE; post = TRT_REF_IDLE; }
-            else if (sp != 0) cur = stk.pop(--sp);
-            else if (post != TRT_REF_IDLE) { cur = post; post = TRT_REF_IDLE; }  // only the parked leaf is left
-            else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; cur = 0u; }
-            else cur = TRT_REF_DONE;
-        }
-        } else {
+        {
         const bool is_inner = !(cur & TRT_LEAF_BIT);
         const bool is_leaf = cur < TRT_REF_DONE && (cur & TRT_LEAF_BIT);
         const unsigned long long m_in = ballotb(is_inner), m_lf = ballotb(is_leaf);
@@ -591,7 +463,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             // ---- inner-node step
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
-                if (innerStep<NK, LdsStack<DEPTH, SPILL>, !(SHADOW && TRT_SHADOW_UNORDERED)>(sc, cur, sp, stk, o, inv, best_t)) { lk = 0; lt = TRT_INF; li = -1; }
+                if (innerStep(sc, cur, sp, stk, o, inv, trt_cull_bound(best_t, sc.leaf_alpha))) { lk = 0; lt = TRT_INF; li = -1; }
                 else adv = true;
             }
         } else {
@@ -616,7 +488,6 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
                             const bool lem = (lflags & 1u) != 0, bem = (best_flags & 1u) != 0;
                             take = lem ? (!bem || li < best_tri) : (!bem && li > best_tri);
                         }
-                        if (NK == 1 && take) take = leafBoxPasses(sc, first, o, inv);  // compressed nodes: the leaf's exact box decides
                         if (take) { best_t = lt; best_tri = li; best_flags = lflags; }
                     }
                     adv = true;
@@ -643,13 +514,126 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
     }
 }
 
+// The same persistent-wave scheduler over the 8-wide compressed nodes (NK = 1, trt_oct.h).  Lane state: the node group it is
+// descending (`ng`: first-child index, hit byte, imask), the triangles it still has to test (`tg`: first record, one bit each), an
+// 8-byte stack entry per level.  A lane with triangle bits waits for a leaf step, one without them for a node step; a wave runs the
+// kind more of its lanes wait for (same weights).  idx == ~0: the lane holds no ray; no work bits and idx != ~0: ray finished, not
+// stored yet.  Results are checked when they are stored (checkedStore<.., OCT>): the ray must pass the exact box of its hit's leaf.
+template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
+__device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
+                                           const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
+{
+    OctLdsStack<DEPTH, SPILL> stk;
+    stk.lds = smem + threadIdx.x;
+    stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
+    stk.spill_stride = spill_stride;
+    const bool any = SHADOW && any_flag;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const uint32_t n_waves = gridDim.x * (TRT_TRACE_BLOCK / 64);
+    const uint32_t wave = xcdSwizzle(blockIdx.x, gridDim.x) * (TRT_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t per = (n + n_waves - 1) / n_waves;
+    const unsigned long long w0 = (unsigned long long)wave * per;
+    uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w0 < n ? w0 : n));
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)((w0 + per) < n ? (w0 + per) : n));
+
+    constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
+    uint32_t idx = NO_RAY, pid = 0;
+    int sp = 0;
+    OctGroup ng, tg;
+    ng.x = 0u; ng.y = 0u; tg.x = 0u; tg.y = 0u;
+    f3 d = mk3(0, 0, 0);
+    OctRay R;
+    R.o = mk3(0, 0, 0); R.inv = mk3(0, 0, 0); R.octinv4 = 0u;
+    float best_t = TRT_INF;
+    int32_t best_tri = -1;
+    uint32_t best_flags = 0;
+    TraceProbe pr;
+
+    for (;;) {
+        const bool working = (tg.y | (ng.y & 0xFF000000u)) != 0u;
+        const bool done = !working && idx != NO_RAY;
+        const unsigned long long m_work = ballotb(working);
+        const unsigned long long m_done = ballotb(done);
+        const unsigned long long m_free = ~m_work;
+        const bool can_fill = next < end;
+        if (m_work == 0ull || (m_done != 0ull && (uint32_t)__popcll(can_fill ? m_free : m_done) >= sc.refill_min)) {
+            if (done) {
+                const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // the exact reciprocals (R.inv has NaN on the axes the node test leaves out)
+                if (checkedStore<SHADOW, true>(sc, R.o, d, inv, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc, any)) redo.idx[atomicAdd(redo.count, 1u)] = idx;
+                idx = NO_RAY;
+            }
+            if (can_fill) {
+                const uint32_t rank = (uint32_t)__popcll(m_free & lower);
+                if (!working && next + rank < end) {
+                    idx = next + rank;
+                    f4 a, b;
+                    fetchRay<PRIMARY>(sc, src, idx, a, b);
+                    d = mk3(a.w, b.x, b.y);
+                    if (SHADOW) pid = f2u(b.z);
+                    R = makeOctRay(mk3(a.x, a.y, a.z), d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));
+                    best_t = SHADOW ? b.w : TRT_INF; best_tri = -1; best_flags = 0u;
+                    sp = 0;
+                    ng.x = 0u; ng.y = 0x80000000u;  // the root
+                    tg.y = 0u;
+                }
+                const uint32_t taken = (uint32_t)__popcll(m_free);
+                next = (end - next) < taken ? end : next + taken;
+            }
+            if (ballotb((tg.y | (ng.y & 0xFF000000u)) != 0u) == 0ull) break;  // nothing left in the slice
+        }
+
+        const bool is_leaf = tg.y != 0u;
+        const bool is_inner = !is_leaf && (ng.y & 0xFF000000u) != 0u;
+        const unsigned long long m_in = ballotb(is_inner), m_lf = ballotb(is_leaf);
+        bool adv = false;  // the lane has used up its groups: next group off the stack, or the ray is finished
+        if (sc.sched_in_w * (uint32_t)__popcll(m_in) >= sc.sched_lf_w * (uint32_t)__popcll(m_lf)) {
+            if (is_inner) {
+                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
+                const uint32_t ni = octNextChild(ng, R);
+                if (ng.y & 0xFF000000u) stk.push(sp++, ng);
+                octVisit(sc.onodes, ni, R, trt_cull_bound(best_t, sc.leaf_alpha), ng, tg);
+                adv = (tg.y | (ng.y & 0xFF000000u)) == 0u;
+            }
+        } else {
+            if (is_leaf) {
+                const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
+                tg.y &= tg.y - 1u;
+                const TriIsect T = sc.tri_trav[tg.x + b];
+                if (COUNT) { pr.n_tri++; if (lane == (uint32_t)__ffsll((long long)m_lf) - 1u) pr.wave_tri++; }
+                float t, un, vn, det;
+                if (triTest(T, R.o, d, t, un, vn, det)) octFold(t, f2u(T.c.w), f2u(T.c.z), best_t, best_tri, best_flags);
+                if (tg.y == 0u) {
+                    if (any && best_tri >= 0) { ng.y = 0u; sp = 0; }  // occlusion test: the first leaf that yields a hit ends the ray
+                    adv = (ng.y & 0xFF000000u) == 0u;
+                }
+            }
+        }
+        if (adv) {
+            if (sp != 0 && !(any && best_tri >= 0)) ng = stk.pop(--sp);
+            else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; ng.x = 0u; ng.y = 0x80000000u; }  // nothing in front of the hint: search again without it
+            else ng.y = 0u;  // finished
+        }
+    }
+    if (COUNT) {
+        const unsigned long long si = waveSum(pr.n_inner), st = waveSum(pr.n_tri), wi = waveSum(pr.wave_inner), wt = waveSum(pr.wave_tri);
+        if (lane == 0) {
+            atomicAdd(&stats->inner_visits[SHADOW ? 1 : 0], si);
+            atomicAdd(&stats->tri_tests[SHADOW ? 1 : 0], st);
+            atomicAdd(&stats->wave_inner_steps, wi);
+            atomicAdd(&stats->wave_leaf_steps, wt);
+        }
+    }
+}
+
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueue(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
 {
     if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats, any_flag, reinterpret_cast<f4*>(smem));
-    else if constexpr (IMPL == 1) traceQueueStatic<SHADOW, COUNT, DEPTH, SPILL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
+    else if constexpr (NK == 1) traceQueuePersistentOct<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
     else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
 }
 
@@ -659,7 +643,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : DEPTH * TRT_TRACE_BLOCK];  // stack, or (uniform walk) the candidate queue
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];  // stack (8-byte entries on the oct tree), or (uniform walk) the candidate queue
     traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false, redo);
 }
 
@@ -671,7 +655,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : DEPTH * TRT_TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;
@@ -679,21 +663,26 @@ __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uin
     traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false, NK>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u, redo);
 }
 
-// The exact form of the traversal for the rays a traversal launch put on its redo list (see RedoList): one block, launched
-// behind every launch of k_trace_closest / k_trace_shadow of a per-lane driver; it finds an empty list all but once in ~10^7 rays.
+// The exact form of the traversal for the rays a traversal launch put on its redo list (see RedoList): a few blocks, launched
+// behind every launch of k_trace_closest / k_trace_shadow of a per-lane driver; it finds an empty list all but once in ~10^7 rays
+// on padded trees.  redo.count[0] = length of the list, redo.count[1] = blocks of this launch that are through: the last one adds
+// the length to DeviceStats::redo_rays (trt_stats.redo_rays: how often the slow path ran is visible to the caller) and empties the list.
+constexpr uint32_t TRT_FIX_BLOCKS = 32;
 template <bool SHADOW, bool PRIMARY, int NK>
 __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_fix(SceneDev sc, RaySource src, f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat,
-                                                               f4* __restrict__ Lacc, uint32_t* __restrict__ spill, uint32_t spill_stride, RedoList redo, uint32_t any_flag)
+                                                               f4* __restrict__ Lacc, uint32_t* __restrict__ spill, uint32_t spill_stride, RedoList redo, uint32_t any_flag,
+                                                               DeviceStats* stats)
 {
     __shared__ __attribute__((aligned(16))) uint32_t smem[TRT_LDS_STACK_MAX * TRT_TRACE_BLOCK];
-    const uint32_t n = *redo.count;  // complete: the traversal launch precedes this one on the stream
-    if (n != 0u) {
+    const uint32_t n = *redo.count;  // complete: the traversal launch precedes this one on the stream; stable until the last block resets it
+    if (n == 0u) return;             // every block sees the same n: all leave here, or none
+    {
         LdsStack<TRT_LDS_STACK_MAX, true> stk;
         stk.lds = smem + threadIdx.x;
-        stk.spill = spill + threadIdx.x;
+        stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
         stk.spill_stride = spill_stride;
         const bool any = SHADOW && any_flag != 0u;
-        for (uint32_t k = threadIdx.x; k < n; k += TRT_TRACE_BLOCK) {
+        for (uint32_t k = blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x; k < n; k += gridDim.x * TRT_TRACE_BLOCK) {
             const uint32_t i = redo.idx[k];
             f4 a, b;
             fetchRay<PRIMARY>(sc, src, i, a, b);
@@ -704,7 +693,14 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_fix(SceneDev sc, RayS
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && n != 0u) *redo.count = 0u;  // ready for the next launch
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(redo.count + 1, 1u) + 1u == gridDim.x) {  // every block has read n and finished its share
+            atomicAdd(&stats->redo_rays, n);
+            redo.count[1] = 0u;
+            redo.count[0] = 0u;  // ready for the next launch
+        }
+    }
 }
 
 

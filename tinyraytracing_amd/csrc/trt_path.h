@@ -125,26 +125,13 @@ struct WideNode {
     f4 q[8];
 };
 
-// Compressed 4-wide inner node, 64 B = four 16-B loads (NK = 1; trt_wide.h compressWide).  A divergent per-lane load costs
-// the CU's texture-address unit one clock per lane whatever it hits (profiles/r02_gather_probe.txt: 0.88 lane-loads per clock
-// and CU from L1 or L2), so a visit that needs four loads instead of seven is what makes the traversal kernels faster.
-//   q[0] = (origin.x, origin.y, origin.z, bits: bytes 0..2 = exponent fields of the per-axis scales 2^(e-127), bits 24..27 = slot used)
-//   q[1] = (lo.x of children 0..3 as four bytes, lo.y, lo.z, hi.x)      q[2] = (hi.y, hi.z, 0, 0)      q[3] = child references
-// A bound is fmaf((float)byte, scale, origin) — evaluated by the builder with this very expression and chosen so that it
-// lies at or outside the exact bound: every stored box CONTAINS the caller's box, is tested by the same slab arithmetic,
-// and by the monotonicity of that test (trt_wide.h) is passed whenever the exact box is.  The traversal therefore reaches
-// a superset of the reference's leaves; a leaf's result is accepted only after the ray has also passed the leaf's EXACT
-// box (leaf_box, fetched only for a leaf that would improve the hit), which restores the reference's set exactly —
-// for a nested tree "passes the exact leaf box" is equivalent to "passes every exact box on the leaf's root path".
-struct CNode {
-    f4 q[4];
-};
-
+struct OctNode;  // trt_oct.h
 struct SceneDev {
     const trt_bvh_node* nodes;   // the caller's BVH2: the wave-uniform walk of tiny trees (trt_kernels.h, IMPL 0)
-    const WideNode* wnodes;      // its 4-wide collapse, exact boxes (NK = 0): trees that are not nested or not compressible
-    const CNode* cnodes;         // the same tree with quantised conservative boxes (NK = 1), same node indices
-    const f4* leaf_box;          // for every triangle i the caller's box of its leaf at [2 i] = (lo.xyz, hi.x), [2 i + 1] = (hi.y, hi.z, -, -): leafEntry(), NK = 1 acceptance
+    const WideNode* wnodes;      // its 4-wide collapse, exact boxes (NK = 0; always present: the exact form of k_trace_fix / k_tail walks it)
+    const OctNode* onodes;       // its 8-wide collapse, quantised conservative boxes (NK = 1, trt_oct.h); null when the tree does not qualify
+    const TriIsect* tri_trav;    // NK = 1: the triangle records in the order the oct nodes address them
+    const f4* leaf_box;          // for every triangle i the caller's box of its leaf at [2 i] = (lo.xyz, hi.x), [2 i + 1] = (hi.y, hi.z, -, -): leafEntry()
     const TriIsect* tri_isect;
     const TriShade* tri_shade;
     const MaterialDev* materials;
@@ -153,12 +140,24 @@ struct SceneDev {
     const float* light_cum;  // light_tris[k].cum_area packed (the CDF of pathTracing.cpp:40); null = scan the structs
     const TextureDev* textures;
     const uint8_t* tex_bytes;
-    uint32_t n_tris, n_nodes, n_wnodes, n_lights;
+    uint32_t n_tris, n_nodes, n_wnodes, n_onodes, n_lights;
     uint32_t refill_min;  // persistent traversal drivers: lanes to have free before a refill (trt_kernels.h)
     uint32_t sched_in_w, sched_lf_w;  // scheduler driver: node step iff sched_in_w * (lanes at nodes) >= sched_lf_w * (lanes at leaves)
     float light0_area;  // Q3: every light's CDF draw spans lights[0].area (pathTracing.cpp:38)
+    float leaf_alpha;   // absolute part of the leaf-box rule's tolerance (trt_leaf_floor, trt_prims.h): sceneLeafAlpha()
     trt_camera cam;
 };
+
+// alpha of the leaf-box rule (trt_prims.h) for a tree: 2^-17 of the largest |coordinate| of the root's two child boxes.
+// The same function on every side (trt_create, the hostsim, the oracle restates it), NaNs ignored.
+TRT_HD inline float sceneLeafAlpha(const trt_bvh_node* nodes, uint32_t n_nodes)
+{
+    if (!n_nodes) return 0.0f;
+    const trt_bvh_node& r = nodes[0];
+    float m = 0.0f;
+    for (int a = 0; a < 3; ++a) m = fmaxf(m, fmaxf(fmaxf(fabsf(r.lo0[a]), fabsf(r.hi0[a])), fmaxf(fabsf(r.lo1[a]), fabsf(r.hi1[a]))));
+    return trt_leaf_alpha(m);
+}
 
 struct Hit {
     float t;         // TRT_INF on a miss (HitRecord::distance default, bvh.h:10)
@@ -316,24 +315,16 @@ TRT_HD inline bool boxTest(float lox, float loy, float loz, float hix, float hiy
         ka = tk_;                                                   \
         ra = tr_;                                                   \
     }
-// NK = 1: the exact box of a leaf (the reference's test of that leaf, bvh.cpp:156-166), for the acceptance of its result
-TRT_HD inline bool leafBoxPasses(const SceneDev& sc, uint32_t first, f3 o, f3 inv)
-{
-    const f4 a = sc.leaf_box[2 * (size_t)first], b = sc.leaf_box[2 * (size_t)first + 1];
-    float e;
-    return boxTest(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, e);
-}
-
-// ORDERED = false: the children that are hit are taken in slot order (the first one next, the others pushed) instead of
-// nearest first.  The hit does not depend on the order (see traceClosest); for a shadow ray that nothing occludes neither does
-// the number of nodes visited — its search is bounded by the distance to the light from the start — so the sort buys nothing there.
 // Entry distance of the box of the leaf triangle `tri` lies in (the caller's box of that leaf, leaf_box).  A triangle hit counts
-// only if it does not lie IN FRONT of its leaf's box (t >= entry): for a ray within ~1e-4 rad of a triangle's plane the
-// Moller-Trumbore distance tn / det can come out well in front of the triangle (its barycentrics are computed independently and
-// still say "inside"), i.e. outside every box that contains the triangle.  The reference never produces such a hit — its
-// inside test is applied to the computed point P = o + d t (bvh.cpp:191-198) — and the rule is what makes culling exact: with
-// every accepted t >= the entry of its leaf's box >= the entries of all boxes above it (nested boxes, monotone slab arithmetic),
-// skipping a node whose entry lies beyond the best hit can never skip a hit that would have beaten it.
+// only if it does not lie IN FRONT of its leaf's box by more than a tolerance: NOT t < trt_leaf_floor(entry, alpha) (trt_prims.h).
+// For a ray within ~1e-4 rad of a triangle's plane the Moller-Trumbore distance tn / det can come out well in front of the
+// triangle (its barycentrics are computed independently and still say "inside"), i.e. outside every box that contains it.  The
+// reference never produces such a hit — its inside test is applied to the computed point P = o + d t (bvh.cpp:191-198) — and
+// the rule is what makes culling exact: every hit that counts has t >= floor(entry of its leaf's box) >= floor(entry of any box
+// above it) (nested boxes, monotone slab arithmetic, monotone floor), so skipping a node whose entry lies beyond
+// trt_cull_bound(best hit) can never skip a hit that would have beaten or tied it.  The tolerance keeps the rule away from honest
+// hits: a triangle ON a face of its leaf's box has entry and tn / det equal up to rounding, and a bare t < entry threw half of
+// those away (unpadded foreign trees; coordinates of 4e4, where the reference's 0.001 pad is below one ulp).
 TRT_HD inline float leafEntry(const SceneDev& sc, uint32_t tri, f3 o, f3 inv)
 {
     const f4 a = sc.leaf_box[2 * (size_t)tri], b = sc.leaf_box[2 * (size_t)tri + 1];
@@ -341,14 +332,16 @@ TRT_HD inline float leafEntry(const SceneDev& sc, uint32_t tri, f3 o, f3 inv)
     (void)boxTest(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, e);
     return e;
 }
+// the distance below which a hit on triangle `tri` does not count
+TRT_HD inline float leafFloor(const SceneDev& sc, uint32_t tri, f3 o, f3 inv) { return trt_leaf_floor(leafEntry(sc, tri, o, inv), sc.leaf_alpha); }
 
-template <int NK, class Stack, bool ORDERED = true>
-TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& stk, f3 o, f3 inv, float best_t)
+// `cull_t` = trt_cull_bound(best hit so far): a child whose entry lies beyond it holds nothing that could still count.
+template <class Stack>
+TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& stk, f3 o, f3 inv, float cull_t)
 {
     float e0, e1, e2, e3;
     bool h0, h1, h2, h3;
     uint32_t r0, r1, r2, r3;
-    if (NK == 0) {
     const f4* np4 = sc.wnodes[cur].q;
     const f4 lx = np4[0], ly = np4[1], lz = np4[2], hx = np4[3], hy = np4[4], hz = np4[5], rf = np4[6];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -363,75 +356,22 @@ TRT_HD inline bool innerStep(const SceneDev& sc, uint32_t& cur, int& sp, Stack& 
     const v2f outx_a = (v2f{lx.x, lx.y} - ox) * ix, outx_b = (v2f{lx.z, lx.w} - ox) * ix;
     const v2f outy_a = (v2f{ly.x, ly.y} - oy) * iy, outy_b = (v2f{ly.z, ly.w} - oy) * iy;
     const v2f outz_a = (v2f{lz.x, lz.y} - oz) * iz, outz_b = (v2f{lz.z, lz.w} - oz) * iz;
-    h0 = slabResult(inx_a.x, iny_a.x, inz_a.x, outx_a.x, outy_a.x, outz_a.x, e0) && !(e0 > best_t);
-    h1 = slabResult(inx_a.y, iny_a.y, inz_a.y, outx_a.y, outy_a.y, outz_a.y, e1) && !(e1 > best_t);
-    h2 = slabResult(inx_b.x, iny_b.x, inz_b.x, outx_b.x, outy_b.x, outz_b.x, e2) && !(e2 > best_t);
-    h3 = slabResult(inx_b.y, iny_b.y, inz_b.y, outx_b.y, outy_b.y, outz_b.y, e3) && !(e3 > best_t);
+    h0 = slabResult(inx_a.x, iny_a.x, inz_a.x, outx_a.x, outy_a.x, outz_a.x, e0) && !(e0 > cull_t);
+    h1 = slabResult(inx_a.y, iny_a.y, inz_a.y, outx_a.y, outy_a.y, outz_a.y, e1) && !(e1 > cull_t);
+    h2 = slabResult(inx_b.x, iny_b.x, inz_b.x, outx_b.x, outy_b.x, outz_b.x, e2) && !(e2 > cull_t);
+    h3 = slabResult(inx_b.y, iny_b.y, inz_b.y, outx_b.y, outy_b.y, outz_b.y, e3) && !(e3 > cull_t);
 #else
-    h0 = boxTest(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, o, inv, e0) && !(e0 > best_t);
-    h1 = boxTest(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, o, inv, e1) && !(e1 > best_t);
-    h2 = boxTest(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, o, inv, e2) && !(e2 > best_t);
-    h3 = boxTest(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, o, inv, e3) && !(e3 > best_t);
+    h0 = boxTest(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, o, inv, e0) && !(e0 > cull_t);
+    h1 = boxTest(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, o, inv, e1) && !(e1 > cull_t);
+    h2 = boxTest(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, o, inv, e2) && !(e2 > cull_t);
+    h3 = boxTest(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, o, inv, e3) && !(e3 > cull_t);
 #endif
     r0 = f2u(rf.x); r1 = f2u(rf.y); r2 = f2u(rf.z); r3 = f2u(rf.w);
-    } else {
-    const f4* np4 = sc.cnodes[cur].q;
-    const f4 fr = np4[0], qa = np4[1], qb = np4[2], rf = np4[3];
-    const uint32_t sw = f2u(fr.w);
-    const float sx = u2f((sw & 0xFFu) << 23), sy = u2f(((sw >> 8) & 0xFFu) << 23), sz = u2f(((sw >> 16) & 0xFFu) << 23);
-    const uint32_t blx = f2u(qa.x), bly = f2u(qa.y), blz = f2u(qa.z), bhx = f2u(qa.w), bhy = f2u(qb.x), bhz = f2u(qb.y);
-#define TRT_B0(w) ((float)((w) & 0xFFu))
-#define TRT_B1(w) ((float)(((w) >> 8) & 0xFFu))
-#define TRT_B2(w) ((float)(((w) >> 16) & 0xFFu))
-#define TRT_B3(w) ((float)((w) >> 24))
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-    const v2f fx = {fr.x, fr.x}, fy = {fr.y, fr.y}, fz = {fr.z, fr.z}, vsx = {sx, sx}, vsy = {sy, sy}, vsz = {sz, sz};
-    // bound = fmaf(byte, scale, origin) (v_pk_fma_f32: one IEEE fma per element), then the slab arithmetic of boxTest()
-    const v2f hx_a = __builtin_elementwise_fma(v2f{TRT_B0(bhx), TRT_B1(bhx)}, vsx, fx), hx_b = __builtin_elementwise_fma(v2f{TRT_B2(bhx), TRT_B3(bhx)}, vsx, fx);
-    const v2f hy_a = __builtin_elementwise_fma(v2f{TRT_B0(bhy), TRT_B1(bhy)}, vsy, fy), hy_b = __builtin_elementwise_fma(v2f{TRT_B2(bhy), TRT_B3(bhy)}, vsy, fy);
-    const v2f hz_a = __builtin_elementwise_fma(v2f{TRT_B0(bhz), TRT_B1(bhz)}, vsz, fz), hz_b = __builtin_elementwise_fma(v2f{TRT_B2(bhz), TRT_B3(bhz)}, vsz, fz);
-    const v2f lx_a = __builtin_elementwise_fma(v2f{TRT_B0(blx), TRT_B1(blx)}, vsx, fx), lx_b = __builtin_elementwise_fma(v2f{TRT_B2(blx), TRT_B3(blx)}, vsx, fx);
-    const v2f ly_a = __builtin_elementwise_fma(v2f{TRT_B0(bly), TRT_B1(bly)}, vsy, fy), ly_b = __builtin_elementwise_fma(v2f{TRT_B2(bly), TRT_B3(bly)}, vsy, fy);
-    const v2f lz_a = __builtin_elementwise_fma(v2f{TRT_B0(blz), TRT_B1(blz)}, vsz, fz), lz_b = __builtin_elementwise_fma(v2f{TRT_B2(blz), TRT_B3(blz)}, vsz, fz);
-    const v2f inx_a = (hx_a - ox) * ix, inx_b = (hx_b - ox) * ix;
-    const v2f iny_a = (hy_a - oy) * iy, iny_b = (hy_b - oy) * iy;
-    const v2f inz_a = (hz_a - oz) * iz, inz_b = (hz_b - oz) * iz;
-    const v2f outx_a = (lx_a - ox) * ix, outx_b = (lx_b - ox) * ix;
-    const v2f outy_a = (ly_a - oy) * iy, outy_b = (ly_b - oy) * iy;
-    const v2f outz_a = (lz_a - oz) * iz, outz_b = (lz_b - oz) * iz;
-    h0 = slabResult(inx_a.x, iny_a.x, inz_a.x, outx_a.x, outy_a.x, outz_a.x, e0) && !(e0 > best_t);
-    h1 = slabResult(inx_a.y, iny_a.y, inz_a.y, outx_a.y, outy_a.y, outz_a.y, e1) && !(e1 > best_t);
-    h2 = slabResult(inx_b.x, iny_b.x, inz_b.x, outx_b.x, outy_b.x, outz_b.x, e2) && !(e2 > best_t);
-    h3 = slabResult(inx_b.y, iny_b.y, inz_b.y, outx_b.y, outy_b.y, outz_b.y, e3) && !(e3 > best_t);
-#else
-    h0 = boxTest(fmaf(TRT_B0(blx), sx, fr.x), fmaf(TRT_B0(bly), sy, fr.y), fmaf(TRT_B0(blz), sz, fr.z), fmaf(TRT_B0(bhx), sx, fr.x), fmaf(TRT_B0(bhy), sy, fr.y), fmaf(TRT_B0(bhz), sz, fr.z), o, inv, e0) && !(e0 > best_t);
-    h1 = boxTest(fmaf(TRT_B1(blx), sx, fr.x), fmaf(TRT_B1(bly), sy, fr.y), fmaf(TRT_B1(blz), sz, fr.z), fmaf(TRT_B1(bhx), sx, fr.x), fmaf(TRT_B1(bhy), sy, fr.y), fmaf(TRT_B1(bhz), sz, fr.z), o, inv, e1) && !(e1 > best_t);
-    h2 = boxTest(fmaf(TRT_B2(blx), sx, fr.x), fmaf(TRT_B2(bly), sy, fr.y), fmaf(TRT_B2(blz), sz, fr.z), fmaf(TRT_B2(bhx), sx, fr.x), fmaf(TRT_B2(bhy), sy, fr.y), fmaf(TRT_B2(bhz), sz, fr.z), o, inv, e2) && !(e2 > best_t);
-    h3 = boxTest(fmaf(TRT_B3(blx), sx, fr.x), fmaf(TRT_B3(bly), sy, fr.y), fmaf(TRT_B3(blz), sz, fr.z), fmaf(TRT_B3(bhx), sx, fr.x), fmaf(TRT_B3(bhy), sy, fr.y), fmaf(TRT_B3(bhz), sz, fr.z), o, inv, e3) && !(e3 > best_t);
-#endif
-#undef TRT_B0
-#undef TRT_B1
-#undef TRT_B2
-#undef TRT_B3
-    h0 = h0 && (sw & (1u << 24)); h1 = h1 && (sw & (1u << 25)); h2 = h2 && (sw & (1u << 26)); h3 = h3 && (sw & (1u << 27));
-    r0 = f2u(rf.x); r1 = f2u(rf.y); r2 = f2u(rf.z); r3 = f2u(rf.w);
-    }
-    if (!ORDERED) {
-        if (!(h0 || h1 || h2 || h3)) return false;
-        // slot order: push the later ones first, so that the earliest hit child is next and the others follow in slot order
-        const bool b3 = h3 && (h0 || h1 || h2), b2 = h2 && (h0 || h1), b1 = h1 && h0;
-        if (b3) stk.push(sp++, r3);
-        if (b2) stk.push(sp++, r2);
-        if (b1) stk.push(sp++, r1);
-        cur = h0 ? r0 : (h1 ? r1 : (h2 ? r2 : r3));
-        return true;
-    }
     const int n = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     if (n == 0) return false;
     // sort by entry distance; children that are not visited get a key no visited one can reach (a visited
-    // entry is <= best_t <= TRT_INF) and so end up last
+    // entry is <= cull_t, a finite bound or +inf when nothing bounds the search: then nothing is skipped by distance and the
+    // only keys of 3e38 belong to children whose box the ray misses) and so end up last
     const float skip = 3.0e38f;
     float k0 = h0 ? e0 : skip, k1 = h1 ? e1 : skip, k2 = h2 ? e2 : skip, k3 = h3 ? e3 : skip;
     TRT_CSWAP(k0, r0, k1, r1)
@@ -498,7 +438,7 @@ TRT_HD inline Hit traceClosestPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, u
 #endif
                     if (COUNT) n_tri++;
                     float t, un, vn, det;
-                    if (triTest(T, o, d, t, un, vn, det) && !(RULE && t < leafEntry(sc, i, o, inv))) {
+                    if (triTest(T, o, d, t, un, vn, det) && !(RULE && t < leafFloor(sc, i, o, inv))) {
                         const uint32_t fl = f2u(T.c.z);
                         if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lun = un; lvn = vn; ldet = det; lflags = fl; }
                     }
@@ -513,7 +453,6 @@ TRT_HD inline Hit traceClosestPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, u
                     const bool lem = (lflags & 1u) != 0, bem = (best.flags & 1u) != 0;
                     take = lem ? (!bem || li < best.tri) : (!bem && li > best.tri);
                 }
-                if (NK == 1 && take) take = leafBoxPasses(sc, first, o, inv);  // the reference never enters a leaf whose own box the ray misses
                 if (take) { best.t = lt; best.tri = li; best.u = lun; best.v = lvn; best_det = ldet; best.flags = lflags; }
             }
             if (sp == 0 || (any && best.tri >= 0)) break;
@@ -521,7 +460,7 @@ TRT_HD inline Hit traceClosestPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, u
             continue;
         }
         if (COUNT) n_inner++;
-        if (!innerStep<NK>(sc, cur, sp, stk, o, inv, best.t)) {
+        if (!innerStep(sc, cur, sp, stk, o, inv, trt_cull_bound(best.t, sc.leaf_alpha))) {
             if (sp == 0) break;
             cur = stk.pop(--sp);
         }
@@ -536,10 +475,10 @@ TRT_HD inline Hit traceClosestPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, u
     return best;
 }
 
-// does the hit (t, tri) lie in front of the box of tri's leaf?  (leafEntry(): such a hit does not count)
+// does the hit (t, tri) lie in front of the box of tri's leaf by more than the tolerance?  (leafFloor(): such a hit does not count)
 TRT_HD inline bool hitInFrontOfItsLeaf(const SceneDev& sc, float t, int32_t tri, f3 o, f3 inv)
 {
-    return tri >= 0 && t < leafEntry(sc, (uint32_t)tri, o, inv);
+    return tri >= 0 && t < leafFloor(sc, (uint32_t)tri, o, inv);
 }
 template <class Stack, bool COUNT, int NK = 0>
 TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false,

@@ -275,102 +275,4 @@ inline std::vector<f4> leafBoxesOf(const trt_bvh_node* nodes2, uint32_t n_nodes2
     return lb;
 }
 
-// ---- compressed nodes (CNode, trt_path.h) ----------------------------------------------------------------------
-// Same topology and node indices as `w`, boxes quantised to 8 bits per bound inside a per-node frame: origin = the
-// per-axis minimum of the children's lower bounds, scale = the smallest power of two for which every bound fits 0..255.
-// Every dequantised bound is evaluated here by the expression the kernels use, fmaf((float)q, scale, origin), and q is
-// moved outward until the stored box contains the exact one.  `leaf_box` receives the exact box of every non-empty leaf
-// (indexed by its first triangle) for the acceptance test of trt_path.h.  ok = false when the tree cannot be walked this
-// way: a box that is not finite or not lo <= hi, or an inner node whose box does not contain its children's (a foreign,
-// non-nested tree: there "passes the leaf's box" does not imply "passes every box above it").
-struct CompressedTree {
-    std::vector<CNode> nodes;
-    std::vector<f4> leaf_box;  // 2 entries per triangle index
-    bool ok = false;
-};
-
-inline CompressedTree compressWide(const WideTree& w, const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t n_tris)
-{
-    using namespace wide_detail;
-    CompressedTree c;
-    // nestedness of the caller's tree: every inner child's stored box contains the boxes stored in that child
-    for (uint32_t n = 0; n < n_nodes2; ++n) {
-        Entry ch[2];
-        children(nodes2[n], ch);
-        for (int k = 0; k < 2; ++k) {
-            for (int a = 0; a < 3; ++a)
-                if (!(std::isfinite(ch[k].b.lo[a]) && std::isfinite(ch[k].b.hi[a]) && ch[k].b.lo[a] <= ch[k].b.hi[a])) return c;
-            if (ch[k].ref & TRT_LEAF_BIT) continue;
-            Entry g[2];
-            children(nodes2[ch[k].ref], g);
-            if (!contains(ch[k].b, g[0].b) || !contains(ch[k].b, g[1].b)) return c;
-        }
-    }
-    c.nodes.resize(w.nodes.size());
-    c.leaf_box.assign((size_t)std::max<uint32_t>(n_tris, 1u) * 2, mk4(0.f, 0.f, 0.f, 0.f));
-    for (size_t i = 0; i < w.nodes.size(); ++i) {
-        const float* q = reinterpret_cast<const float*>(w.nodes[i].q);
-        const uint32_t* qu = reinterpret_cast<const uint32_t*>(w.nodes[i].q);
-        uint32_t ref[TRT_WIDE];
-        bool used[TRT_WIDE];
-        float origin[3], scale[3];
-        uint32_t ebits[3];
-        for (int k = 0; k < TRT_WIDE; ++k) { ref[k] = qu[6 * 4 + k]; used[k] = ref[k] != TRT_WIDE_EMPTY; }
-        uint32_t qlo[3][TRT_WIDE] = {}, qhi[3][TRT_WIDE] = {};
-        for (int a = 0; a < 3; ++a) {
-            float mn = 0.f, mx = 0.f;
-            bool any = false;
-            for (int k = 0; k < TRT_WIDE; ++k) {
-                if (!used[k]) continue;
-                const float lo = q[a * 4 + k], hi = q[(3 + a) * 4 + k];
-                if (!any) { mn = lo; mx = hi; any = true; }
-                else { mn = std::fmin(mn, lo); mx = std::fmax(mx, hi); }
-            }
-            origin[a] = mn;
-            // smallest power of two with (mx - mn) / scale <= 252: three steps of headroom for the outward corrections
-            const double ext = (double)mx - (double)mn;
-            int e = 0;
-            if (ext > 0.0) { (void)std::frexp(ext / 252.0, &e); }  // ext / 252 = m * 2^e, m in [0.5, 1): 2^e >= ext / 252
-            else e = -126;
-            int eb = e + 127;
-            if (eb < 1) eb = 1;
-            if (eb > 254) { c.nodes.clear(); c.leaf_box.clear(); return c; }
-            ebits[a] = (uint32_t)eb;
-            scale[a] = u2f((uint32_t)eb << 23);
-            for (int k = 0; k < TRT_WIDE; ++k) {
-                if (!used[k]) continue;
-                const float lo = q[a * 4 + k], hi = q[(3 + a) * 4 + k];
-                long ql = (long)std::floor(((double)lo - (double)mn) / (double)scale[a]);
-                if (ql < 0) ql = 0;
-                if (ql > 255) ql = 255;
-                while (ql > 0 && fmaf((float)ql, scale[a], origin[a]) > lo) --ql;
-                long qh = (long)std::ceil(((double)hi - (double)mn) / (double)scale[a]);
-                if (qh < 0) qh = 0;
-                while (qh < 255 && fmaf((float)qh, scale[a], origin[a]) < hi) ++qh;
-                if (qh > 255 || fmaf((float)ql, scale[a], origin[a]) > lo || fmaf((float)qh, scale[a], origin[a]) < hi) { c.nodes.clear(); c.leaf_box.clear(); return c; }
-                qlo[a][k] = (uint32_t)ql;
-                qhi[a][k] = (uint32_t)qh;
-            }
-        }
-        auto pack = [](const uint32_t v[TRT_WIDE]) { return v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24); };
-        uint32_t sw = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16);
-        for (int k = 0; k < TRT_WIDE; ++k)
-            if (used[k]) sw |= 1u << (24 + k);
-        CNode cn;
-        cn.q[0] = mk4(origin[0], origin[1], origin[2], u2f(sw));
-        cn.q[1] = mk4(u2f(pack(qlo[0])), u2f(pack(qlo[1])), u2f(pack(qlo[2])), u2f(pack(qhi[0])));
-        cn.q[2] = mk4(u2f(pack(qhi[1])), u2f(pack(qhi[2])), 0.f, 0.f);
-        cn.q[3] = mk4(u2f(ref[0]), u2f(ref[1]), u2f(ref[2]), u2f(ref[3]));
-        c.nodes[i] = cn;
-        for (int k = 0; k < TRT_WIDE; ++k) {
-            if (!used[k] || !(ref[k] & TRT_LEAF_BIT) || TRT_LEAF_COUNT(ref[k]) == 0) continue;
-            const size_t first = TRT_LEAF_FIRST(ref[k]);
-            c.leaf_box[2 * first] = mk4(q[0 * 4 + k], q[1 * 4 + k], q[2 * 4 + k], q[3 * 4 + k]);
-            c.leaf_box[2 * first + 1] = mk4(q[4 * 4 + k], q[5 * 4 + k], 0.f, 0.f);
-        }
-    }
-    c.ok = true;
-    return c;
-}
-
 }  // namespace trtd
