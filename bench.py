@@ -114,6 +114,14 @@ class Bench:
         t_load = time.time() - t0
         renderer = T.Renderer(scene, local_rank)
         budget = int(a.mem_gb * (1 << 30))
+        group = None
+        if a.group > 0 and world == 1:
+            # --group N: the C boundary of the multi-GPU path (trt_group_render_device: resident host threads, interleaved stripes, gather,
+            # un-interleave; image left on the first device) with N entries naming this device — all its overhead, none of its speed-up
+            renderer.close()
+            group = T.GroupRenderer(scene, [local_rank] * a.group)
+            if budget == 0:  # N handles share one device's memory: give each its share instead of three quarters of what is free
+                budget = int(torch.cuda.mem_get_info(local_rank)[0] * 0.6 / a.group)
         fx = T.TRT_FLAG_FIXED_NEE if a.fixed_nee else 0
         # The timed steps run WITHOUT TRT_FLAG_TIMING (two hipEventRecords per launch, ~60 launches per step: at one rank of eight a
         # step is ~12 ms and they show); per-kernel times come from ONE extra step with the events on, after the timed region.
@@ -126,6 +134,11 @@ class Bench:
         stream = torch.cuda.current_stream().cuda_stream
 
         def step(flags):
+            if group is not None:
+                pg = T.make_params(width, height, spp, seed, flags=flags, mem_budget=budget)
+                st_g, _ = group.render_into(pg, out)
+                return out, st_g
+
             def fn(pp):
                 return out, renderer.render_into(pp, out, stream)
             # every rank renders its stripes, then ONE gather of the packed stripes to rank 0
@@ -216,6 +229,7 @@ class Bench:
                            "leaf_num": leaf if leaf is not None else T.default_leaf(scene_name, scene.info["n_triangles"]),
                            "inner_node_bytes": st_count.inner_node_bytes,
                            "overlap_passes": bool(base_flags & T.TRT_FLAG_OVERLAP), "fixed_nee": bool(a.fixed_nee),
+                           "group_entries_on_this_device": a.group if group is not None else None,
                            "tiling": "single GPU" if world == 1 else f"rows interleaved in 8-row stripes over {world} GPUs + one RCCL gather"},
                 "rays_per_step": rays_total // steps,
                 "rays_rank0": {"camera": st.rays_camera, "shadow": st.rays_shadow, "indirect": st.rays_indirect},
@@ -232,13 +246,35 @@ class Bench:
             if save_png and img is not None:
                 T.imshow(img.cpu().numpy(), save_png)
         renderer.close()
+        if group is not None:
+            group.close()
         del out
         torch.cuda.empty_cache()
         return res, scene
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks (one process per GPU) the way the contract's
+    launcher does — python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 — as a CHILD process, before
+    this process has imported torch or touched a GPU (an exec after GPU initialisation is not allowed on this pool), relay its output
+    and exit with its return code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"bench.py: --gpus {a.gpus} without WORLD_SIZE: launching {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
     import torch
     import tinyraytracing_amd as T
 
@@ -246,8 +282,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -269,7 +303,7 @@ def main():
     B = Bench(a, world, rank, local_rank, dist, backend)
     seed = a.seed if a.seed is not None else SEEDS[a.scene]
     res, scene = B.measure(a.scene, a.width, a.height, a.spp, a.steps, a.warmup, seed, leaf=a.leaf, tris=a.tris,
-                           base_flags=T.TRT_FLAG_OVERLAP if a.overlap else 0, also_overlap=a.also_overlap, save_png=a.save_png)
+                           base_flags=T.TRT_FLAG_OVERLAP if a.overlap else 0, also_overlap=not a.no_overlap_extra, save_png=a.save_png)
     if rank == 0:
         result = {"metric": "Mrays/s", "value": res["value"], "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                   "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32"}

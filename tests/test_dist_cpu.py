@@ -29,7 +29,16 @@ img, st = D.render_distributed(render_fn, 40, 30, 3, 9, dist=dist, row_block=4)
 rays = torch.tensor([st.rays_camera + st.rays_shadow + st.rays_indirect], dtype=torch.int64)
 dist.all_reduce(rays)
 if dist.get_rank() == 0:
-    np.savez({out!r}, image=img.numpy(), rays=rays.numpy())
+    np.savez({out!r}, image=img.numpy().copy(), rays=rays.numpy())
+# ADVICE r02: two image heights with the same padded stripe height (8 rows per rank at heights 16 and 12) in one process:
+# rank 0's cached landing buffers must follow the height (a stale key returned an image of the old height)
+for h2 in (16, 12, 16):
+    sc2 = T.Scene.named("back", 24, h2)
+    im2, _ = D.render_distributed(lambda p: O.render(sc2.flat, p, threads=2), 24, h2, 1, 4, dist=dist, row_block=8)
+    if dist.get_rank() == 0:
+        ref2, _ = O.render(sc2.flat, T.make_params(24, h2, 1, 4), threads=2)
+        assert tuple(im2.shape) == (h2, 24, 3), im2.shape
+        assert np.array_equal(im2.numpy(), ref2)
 dist.destroy_process_group()
 '''
 
@@ -75,3 +84,17 @@ def test_two_rank_gloo_render_equals_single_process(tmp_path):
     ref, st = O.render(scene.flat, T.make_params(40, 30, 3, 9))
     assert np.array_equal(got["image"], ref)            # independent of the number of ranks, bit for bit
     assert int(got["rays"][0]) == st.rays
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE (how the driver may start the scaling runs): bench.py starts
+    torch.distributed.run as a child before touching torch or a GPU and exits with the child's return code.  On this CPU-only
+    container the two ranks come up, find no GPU and say so — which proves the launch plumbing; the GPU box runs the real thing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert "launching -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1" in r.stderr, r.stderr[-2000:]
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+        assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]

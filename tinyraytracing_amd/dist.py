@@ -95,7 +95,7 @@ def render_distributed(render_fn, width, height, spp, seed, dist=None, device=No
     # rank 0's landing buffers are kept between calls (bench.py calls this once per step: at 8 ranks a step is ~12 ms)
     gather_list = None
     if rank == 0:
-        key = (pad_rows, width, world, str(buf.device))
+        key = (height, pad_rows, width, world, row_block, str(buf.device))  # the image buffer hangs on the height, the stripes on row_block
         if key not in _gather_cache:
             _gather_cache.clear()
             _gather_cache[key] = ([torch.empty_like(buf) for _ in range(world)], torch.empty((height, width, 3), dtype=torch.float32, device=buf.device))

@@ -24,10 +24,10 @@ def main():
     for name, (w, h) in sizes.items():
         scenes[name] = T.Scene.named(name, w, h, **({"n": 50000} if name == "soup" else {}))
         renderers[name] = T.Renderer(scenes[name], 0)
-        # a second handle per scene on the optional code paths: quantised nodes + speculative scheduler (per-lane scenes),
-        # per-lane traversal instead of the uniform walk (tiny scene)
-        os.environ["TRT_NODE_KIND"] = "1"
-        os.environ["TRT_TRACE_IMPL"] = "4" if name != "back" else "3"
+        # a second handle per scene on the OTHER node kind of the traversal kernels (exact 4-wide nodes where the default is the 8-wide
+        # compressed ones), and per-lane traversal instead of the uniform walk for the tiny scene
+        os.environ["TRT_NODE_KIND"] = "0"
+        os.environ["TRT_TRACE_IMPL"] = "3"
         alt[name] = T.Renderer(scenes[name], 0)
         del os.environ["TRT_NODE_KIND"], os.environ["TRT_TRACE_IMPL"]
     t0 = time.time()

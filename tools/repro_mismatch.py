@@ -13,7 +13,7 @@ w, h = sizes[name]
 sc = T.Scene.named(name, w, h, **({"n": 50000} if name == "soup" else {}))
 p = T.make_params(w, h, spp, seed, tile=(x0, y0, x1, y1), rows=(rb, rm, rr) if rm > 1 else None, max_depth=md, flags=flags)
 ref, ost = O.render(sc.flat, p)
-for label, env in (("default", {}), ("alt", {"TRT_NODE_KIND": "1", "TRT_TRACE_IMPL": "4" if name != "back" else "3"}), ("impl3", {"TRT_TRACE_IMPL": "3"}), ("impl2", {"TRT_TRACE_IMPL": "2"}), ("impl1", {"TRT_TRACE_IMPL": "1"})):
+for label, env in (("default", {}), ("exact 4-wide nodes, per lane", {"TRT_NODE_KIND": "0", "TRT_TRACE_IMPL": "3"}), ("8-wide compressed nodes, per lane", {"TRT_NODE_KIND": "1", "TRT_TRACE_IMPL": "3"})):
     os.environ.update(env)
     r = T.Renderer(sc, 0)
     for k in env: del os.environ[k]
