@@ -41,6 +41,13 @@ int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, o
  * mode only (max_depth 0, no TRT_FLAG_FIXED_*).  Used to measure and freeze the stated tolerance between the
  * reference's formulation and the one the HIP kernels share with oracle_render(). */
 int oracle_render_literal(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats, int threads);
+/* Experiments on what the parity path does NOT take from the reference — its unsynchronised accumulation (main.cpp:79-81,103-108) and
+ * its five shared random engines, three of them seeded alike (main.cpp:57, pathTracing.cpp:33,106,113,149) — to measure how much of the
+ * brightness gap to the reference's saved renders they account for (tests/test_ref_png.py).  Whole image only. */
+#define ORACLE_EXP_RACY_ACCUM 1
+#define ORACLE_EXP_SHARED_ENGINES 2
+#define ORACLE_EXP_INDEPENDENT_ENGINES 3
+int oracle_render_literal_experiment(const trt_scene* scene, const trt_params* p, float* out_rgb, int threads, int experiment);
 /* interactTriangle + findBaryCor literally on one triangle: returns 1 on hit, out = {t, b0, b1, b2}. */
 int oracle_tri_test_literal(const float v[9], const float o[3], const float d[3], float out[4]);
 /* traverseBVH with the literal triangle test on a ray batch (uv = barycentric weights of v1, v2 from findBaryCor). */

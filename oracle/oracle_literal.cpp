@@ -38,6 +38,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "trt_prims.h"
@@ -146,10 +147,26 @@ struct Counters {
     uint32_t max_bounces = 0;
 };
 
+// Which of the reference's five engines a draw comes from (main.cpp:57, pathTracing.cpp:33,106,113,149).
+enum { ENG_MAIN = 0, ENG_SHADE = 1, ENG_RR = 2, ENG_SAMPLE = 3, ENG_NEXTRAY = 4 };
+// EXPERIMENT (oracle_render_literal_experiment): the reference's own random sources — five function-local static
+// std::default_random_engine objects shared by every sample.  MSVC's default_random_engine is mt19937; main's is seeded with
+// time(NULL) before the scene is loaded, shade's, Sample's and nextRay's with time(NULL) at their first call (the same second:
+// IDENTICAL streams), RR's is default-seeded.  uniform_real_distribution<double> takes two 32-bit outputs per draw.
+struct Engines {
+    std::mt19937 e[5];
+    std::uniform_real_distribution<double> u{0.0, 1.0};
+    Engines(uint32_t seed_main, uint32_t seed_shade, uint32_t seed_sample, uint32_t seed_nextray)
+    {
+        e[ENG_MAIN].seed(seed_main); e[ENG_SHADE].seed(seed_shade); e[ENG_SAMPLE].seed(seed_sample); e[ENG_NEXTRAY].seed(seed_nextray);
+        e[ENG_RR].seed(std::mt19937::default_seed);
+    }
+};
 struct Stream {
     trt_rng_key key;
     uint32_t ctr;
-    double next() { return (double)trt_rng_uniform(key, ctr++); }  // the reference's distributions are double
+    Engines* eng = nullptr;  // experiment only: draws come from the shared engines instead of the per-sample counter stream
+    double next(int which) { return eng ? eng->u(eng->e[which]) : (double)trt_rng_uniform(key, ctr++); }  // the reference's distributions are double
 };
 
 struct Literal {
@@ -270,10 +287,10 @@ struct Literal {
     // pathTracing.cpp:111-145
     static V3 Sample(V3 direction, int ray_type, double Ns, Stream& rng)
     {
-        const double phi = rng.next() * 2 * (double)TRT_PI;
+        const double phi = rng.next(ENG_SAMPLE) * 2 * (double)TRT_PI;
         double theta;
-        if (ray_type == TRT_RAY_DIFFUSE) theta = std::asin(std::sqrt(rng.next()));
-        else theta = std::acos(std::pow(rng.next(), (double)1 / (Ns + 1)));
+        if (ray_type == TRT_RAY_DIFFUSE) theta = std::asin(std::sqrt(rng.next(ENG_SAMPLE)));
+        else theta = std::acos(std::pow(rng.next(ENG_SAMPLE), (double)1 / (Ns + 1)));
         const V3 sample = mk((float)(std::sin(theta) * std::cos(phi)), (float)std::cos(theta), (float)(std::sin(theta) * std::sin(phi)));
         V3 front;
         if (fabsf(direction.x) > fabsf(direction.y)) front = normalize(mk(direction.z, 0, -direction.x));
@@ -293,7 +310,7 @@ struct Literal {
             else { normal = pn; n1 = 1.0; n2 = m.Ni; }
             const double rf0 = std::pow((n1 - n2) / (n1 + n2), 2);
             const double fresnel = rf0 + (1.0f - rf0) * std::pow(1.0f - std::abs(cos_in), 5);
-            if (fresnel < rng.next()) {
+            if (fresnel < rng.next(ENG_NEXTRAY)) {
                 next_dir = refract(ray_direction, normal, (float)(n1 / n2));
                 if (next_dir.x != 0.0f || next_dir.y != 0.0f || next_dir.z != 0.0f) return TRT_RAY_TRANSMISSION;
                 next_dir = reflect(ray_direction, normal);
@@ -302,7 +319,7 @@ struct Literal {
         }
         const double Kd_len = length(ld(m.Kd)), Ks_len = length(ld(m.Ks));
         const double kd = Kd_len / (Kd_len + Ks_len), ks = Ks_len / (Kd_len + Ks_len);
-        const double p = rng.next();
+        const double p = rng.next(ENG_NEXTRAY);
         if (p < kd) {
             next_dir = Sample(pn, TRT_RAY_DIFFUSE, m.Ns, rng);
             return TRT_RAY_DIFFUSE;
@@ -345,11 +362,11 @@ struct Literal {
         for (uint32_t li = 0; li < s->n_lights; ++li) {
             const trt_light& L = s->lights[li];
             const double total_area = light_area[li];
-            const double rnd = rng.next() * area0;
+            const double rnd = rng.next(ENG_SHADE) * area0;
             for (uint32_t k = 0; k < L.tri_count; ++k) {
                 if (!(rnd < light_cum[li][k])) continue;
                 const trt_light_tri& lt = s->light_tris[L.tri_first + k];
-                const double rnd1 = rng.next(), rnd2 = rng.next(), rnd3 = rng.next();
+                const double rnd1 = rng.next(ENG_SHADE), rnd2 = rng.next(ENG_SHADE), rnd3 = rng.next(ENG_SHADE);
                 const float p1 = (float)(rnd1 / (rnd1 + rnd2 + rnd3)), p2 = (float)(rnd2 / (rnd1 + rnd2 + rnd3)), p3 = (float)(rnd3 / (rnd1 + rnd2 + rnd3));
                 const V3 light_p = (ld(lt.v[0]) * p1 + ld(lt.v[1]) * p2) + ld(lt.v[2]) * p3;
                 const V3 light_n = normalize((ld(lt.vn[0]) * p1 + ld(lt.vn[1]) * p2) + ld(lt.vn[2]) * p3);
@@ -372,7 +389,7 @@ struct Literal {
                 break;
             }
         }
-        if (rng.next() < (double)TRT_P_RR) {  // RR(P_RR), :104-109
+        if (rng.next(ENG_RR) < (double)TRT_P_RR) {  // RR(P_RR), :104-109
             V3 nd;
             const int type = nextRay(m, rec.pn, -wi, rng, nd);
             if (type != TRT_RAY_INVALID) {
@@ -428,8 +445,8 @@ int oracle_render_literal(const trt_scene* scene, const trt_params* p, float* ou
                     Stream rng{trt_rng_make_key(p->seed, pixel, (uint32_t)k), 0};
                     double x = double(j) / double(p->width - 1.0);      // main.cpp:88-93
                     double y = double(p->height - i) / double(p->height - 1.0);
-                    x += (rng.next() - 0.5f) / double(p->width);
-                    y += (rng.next() - 0.5f) / double(p->height);
+                    x += (rng.next(ENG_MAIN) - 0.5f) / double(p->width);
+                    y += (rng.next(ENG_MAIN) - 0.5f) / double(p->height);
                     // camera.cpp:19-28
                     const trt_camera& cam = scene->camera;
                     const float sf = (float)x, tf = (float)y;
@@ -467,6 +484,63 @@ int oracle_render_literal(const trt_scene* scene, const trt_params* p, float* ou
         stats->threads = threads;
         stats->seconds = std::chrono::duration<double>(t_end - t_begin).count();
     }
+    return TRT_OK;
+}
+
+/* EXPERIMENTS on the two things the parity path deliberately does NOT take from the reference (oracle.h): its accumulation and its
+ * random sources.  The loop nest is main.cpp:80-113's: samples outermost, then rows, then columns, color / SAMPLE added to one shared
+ * double image.
+ *   ORACLE_EXP_RACY_ACCUM: `threads` OpenMP threads over the SAMPLE index, every one of them sweeping the whole image and adding into
+ *     the same pixels WITHOUT synchronisation (main.cpp:79-81,103-108).  Draws stay the per-sample counter streams, so the race-free sum is
+ *     oracle_render_literal's image exactly and the difference is the mass lost to overwritten updates.  A real data race, on purpose;
+ *     never run under a sanitizer.
+ *   ORACLE_EXP_SHARED_ENGINES: one thread; the draws come from the reference's five engines (struct Engines): main's seeded p->seed,
+ *     shade's, Sample's and nextRay's ALL seeded p->seed + 1 (identical streams, as time(NULL) leaves them), RR's default-seeded.
+ *   ORACLE_EXP_INDEPENDENT_ENGINES: the same with three different seeds (the control: what changing the generator alone does). */
+int oracle_render_literal_experiment(const trt_scene* scene, const trt_params* p, float* out_rgb, int threads, int experiment)
+{
+    if (!scene || !p || !out_rgb) return TRT_EINVAL;
+    if (p->width < 2 || p->height < 2 || p->spp < 1 || scene->n_nodes < 1 || !scene->nodes) return TRT_EINVAL;
+    if (p->x0 != 0 || p->y0 != 0 || p->x1 != p->width || p->y1 != p->height || p->row_mod > 1 || p->max_depth != 0 || p->flags != 0) return TRT_EINVAL;
+    const bool racy = experiment == ORACLE_EXP_RACY_ACCUM;
+    if (!racy && experiment != ORACLE_EXP_SHARED_ENGINES && experiment != ORACLE_EXP_INDEPENDENT_ENGINES) return TRT_EINVAL;
+    Literal lit(scene);
+    const int W = p->width, H = p->height, SAMPLE = p->spp;
+    std::vector<double> image((size_t)W * H * 3, 0.0);  // main.cpp:74-75
+    Engines eng(p->seed, p->seed + 1u, experiment == ORACLE_EXP_SHARED_ENGINES ? p->seed + 1u : p->seed + 2u,
+                experiment == ORACLE_EXP_SHARED_ENGINES ? p->seed + 1u : p->seed + 3u);
+    if (threads <= 0) threads = omp_get_num_procs();
+    if (!racy) threads = 1;
+    double* const base = image.data();
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int k = 0; k < SAMPLE; k++) {
+        Counters cnt;
+        double* px = base;
+        for (int i = 0; i < H; i++) {
+            for (int j = 0; j < W; j++) {
+                Stream rng{trt_rng_make_key(p->seed, (uint32_t)i * (uint32_t)W + (uint32_t)j, (uint32_t)k), 0, racy ? nullptr : &eng};
+                double x = double(j) / double(W - 1.0);
+                double y = double(H - i) / double(H - 1.0);
+                x += (rng.next(ENG_MAIN) - 0.5f) / double(W);
+                y += (rng.next(ENG_MAIN) - 0.5f) / double(H);
+                const trt_camera& cam = scene->camera;
+                const float sf = (float)x, tf = (float)y;
+                const V3 eye = ld(cam.eye);
+                const V3 dir = normalize(((ld(cam.lower_left_corner) + ld(cam.horizontal) * sf) + ld(cam.vertical) * tf) - eye);
+                const HitRecord rec = lit.traverseBVH(eye, dir);
+                V3 color = mk(0, 0, 0);
+                if (rec.is_hit) color = lit.shade(rec, -dir, rng, cnt, 0) / (float)SAMPLE;
+                // main.cpp:103-108: unsynchronised read-modify-write of shared memory (volatile: one load and one store per
+                // statement, as the reference's compiled loop has them, instead of whatever the optimiser would merge)
+                volatile double* q = px;
+                q[0] = q[0] + color.x;
+                q[1] = q[1] + color.y;
+                q[2] = q[2] + color.z;
+                px += 3;
+            }
+        }
+    }
+    for (size_t i = 0; i < image.size(); ++i) out_rgb[i] = (float)image[i];
     return TRT_OK;
 }
 

@@ -229,6 +229,48 @@ extern "C" int hostsim_trace(const trt_scene* s, uint64_t n, const float* org, c
     return 0;
 }
 
+// how many of the rays take the exact form behind the oct traversal (its result failed octResultCounts): tests/test_hostsim_parity.py
+extern "C" uint64_t hostsim_oct_fallbacks(const trt_scene* s, uint64_t n, const float* org, const float* dir)
+{
+    const int old = g_node_kind;
+    g_node_kind = 1;
+    HostScene hs(s);
+    g_node_kind = old;
+    if (!hs.nk) return ~0ull;
+    uint64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (long long i = 0; i < (long long)n; ++i) {
+        OctArrayStack ostk;
+        uint32_t ni = 0, nt = 0;
+        const f3 o = ld3(org + i * 3), d = ld3(dir + i * 3);
+        const Hit h = traceOctPass<OctArrayStack, false>(hs.sc, o, d, ostk, ni, nt, TRT_INF, false, false);
+        bad += octResultCounts(hs.sc, h.t, h.tri, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)) ? 0u : 1u;
+    }
+    return bad;
+}
+
+// per-ray work of the closest-hit search on either node kind: visits[i], tests[i] (tools / tests: where do the long traversals come from?)
+extern "C" int hostsim_trace_counts(const trt_scene* s, int nk, uint64_t n, const float* org, const float* dir, uint32_t* visits, uint32_t* tests)
+{
+    const int old = g_node_kind;
+    g_node_kind = nk;
+    HostScene hs(s);
+    g_node_kind = old;
+    if (nk && !hs.nk) return 1;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long long i = 0; i < (long long)n; ++i) {
+        ArrayStack stk;
+        OctArrayStack ostk;
+        uint32_t ni = 0, nt = 0;
+        const f3 o = ld3(org + i * 3), d = ld3(dir + i * 3);
+        if (hs.nk) (void)traceOctPass<OctArrayStack, true>(hs.sc, o, d, ostk, ni, nt, TRT_INF, false, false);
+        else (void)traceClosestPass<ArrayStack, true, 0, false>(hs.sc, o, d, stk, ni, nt);
+        visits[i] = ni;
+        tests[i] = nt;
+    }
+    return 0;
+}
+
 // divMagic(n, d, magicOf(d)) against n / d for a list of numerators: returns the number of mismatches (tests/test_hostsim_parity.py)
 extern "C" uint64_t hostsim_div_magic_mismatches(uint32_t d, const uint32_t* n, uint64_t count)
 {

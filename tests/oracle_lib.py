@@ -90,6 +90,20 @@ def render_literal(flat, params, threads=0):
     return out, st
 
 
+EXP_RACY_ACCUM, EXP_SHARED_ENGINES, EXP_INDEPENDENT_ENGINES = 1, 2, 3
+
+
+def render_literal_experiment(flat, params, experiment, threads=0):
+    """oracle_render_literal_experiment (oracle.h): the reference's racy accumulation / its shared random engines.  Whole image."""
+    out = np.empty((params.height, params.width, 3), np.float32)
+    L = lib()
+    L.oracle_render_literal_experiment.argtypes = [C.POINTER(SceneFlat), C.POINTER(Params), fp, C.c_int, C.c_int]
+    rc = L.oracle_render_literal_experiment(flat, C.byref(params), out.ctypes.data_as(fp), int(threads), int(experiment))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render_literal_experiment failed: {rc}")
+    return out
+
+
 def trace_literal(flat, org, direction):
     org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
     direction = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)

@@ -169,6 +169,32 @@ def test_compressed_nodes_give_the_same_hits_and_image(name):
         H.set_node_kind(old)
 
 
+@pytest.mark.parametrize("name", ["staircase", "veach-mis"])
+def test_axis_aligned_rays_stay_cheap_on_the_oct_nodes(name):
+    """A direction component that is exactly zero (camera rays of an axis-aligned camera: d.x is a difference of numbers near the eye's
+    coordinate and comes out as exactly 0 for one pixel column in ~40 000) must not drop out of the node test: the first version of
+    trt_oct.h left such an axis unconstrained — exact, but the ray then visited every node of a slab of the scene (1 500 nodes and 4 600
+    triangles on the 2 M-triangle mesh: one GPU lane busy for milliseconds, 100x on the whole kernel).  With the axis tested as the
+    reference tests it (origin between the planes or not) the longest traversal is of the order of the exact nodes' longest one."""
+    s = get_scene(name, 160, 90)
+    lo, hi = raygen.scene_bounds(s)
+    rng = np.random.default_rng(3)
+    n = 30000
+    org = (rng.random((n, 3)) * (hi - lo) + lo).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[np.arange(n), rng.integers(0, 3, n)] = 0.0       # one component exactly zero ...
+    two = rng.random(n) < 0.2
+    d[two, rng.integers(0, 3, int(two.sum()))] = 0.0   # ... or two
+    d[np.abs(d).sum(1) == 0] = (0.0, 0.0, 1.0)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    v0, t0 = H.trace_counts(s.flat, 0, org, d)
+    v1, t1 = H.trace_counts(s.flat, 1, org, d)
+    assert v1.mean() <= v0.mean()                      # still fewer node visits than the 4-wide tree
+    assert int(v1.max()) <= 2 * int(v0.max()) + 16, (int(v0.max()), int(v1.max()))
+    assert int(t1.max()) <= 3 * int(t0.max()) + 48, (int(t0.max()), int(t1.max()))
+    assert H.oct_fallbacks(s.flat, org, d) <= 3        # and the results of such rays pass the check like any other
+
+
 def test_foreign_tree_is_not_compressed():
     """A tree whose boxes are not nested (a child's box sticks out of its parent's) cannot use the leaf-box argument."""
     import scene_util as SU

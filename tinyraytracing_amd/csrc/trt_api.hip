@@ -297,17 +297,13 @@ struct Timer {
     hipLaunchKernelGGL((k_trace_shadow<COUNT, DEPTH, SPILL, IMPL, NK>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any, redo)
 #define TRT_BY_DEPTH(LAUNCH, IMPL, NK)                                       \
     do {                                                                     \
-        if (h->depth <= 8) LAUNCH(8, false, IMPL, NK);                       \
-        else if (h->depth <= 16) LAUNCH(16, false, IMPL, NK);                \
+        if (h->depth <= 16) LAUNCH(16, false, IMPL, NK);                     \
         else LAUNCH(TRT_LDS_STACK_MAX, true, IMPL, NK);                      \
     } while (0)
-// the oct tree needs one 8-byte entry per level below the root
-constexpr uint32_t OCT_LDS_SHALLOW = 8, OCT_LDS_DEEP = 12;
-#define TRT_BY_OCT_DEPTH(LAUNCH)                                             \
-    do {                                                                     \
-        if (h->oct_levels <= OCT_LDS_SHALLOW + 1) LAUNCH(8, false, 3, 1);    \
-        else LAUNCH(12, true, 3, 1);                                         \
-    } while (0)
+// The oct tree needs one 8-byte entry per level below the root: OCT_LDS_LEVELS of them in LDS (20 KiB per block: eight blocks per CU),
+// deeper ones — staircase has 10 levels, the 10 M-triangle mesh 11 — in the global spill area.  One instantiation serves every tree.
+constexpr uint32_t OCT_LDS_LEVELS = 10;
+#define TRT_BY_OCT_DEPTH(LAUNCH) LAUNCH(10, true, 3, 1)
 // Behind every traversal launch of a per-lane driver: k_trace_fix (a few blocks) traces the rays of the launch's redo list again in the
 // exact form (trt_kernels.h, RedoList).  The wave-uniform walk applies the rule on the spot and has no list.
 template <bool COUNT, bool PRIMARY>
@@ -547,7 +543,7 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
     uint32_t spill_levels = h->depth > (uint32_t)TRT_LDS_STACK_MAX ? h->depth - TRT_LDS_STACK_MAX + 1 : 1;
-    if (h->node_kind == 1 && h->oct_levels > OCT_LDS_DEEP) spill_levels = std::max(spill_levels, 2u * (h->oct_levels - OCT_LDS_DEEP + 1));  // two words per level
+    if (h->node_kind == 1 && h->oct_levels > OCT_LDS_LEVELS) spill_levels = std::max(spill_levels, 2u * (h->oct_levels - OCT_LDS_LEVELS + 1));  // two words per level
     h->spill_words_per_slot = (size_t)spill_levels * SPILL_STRIDE;
     if (int e = h->spill.ensure(h->spill_words_per_slot * 2 * sizeof(uint32_t))) return e;  // one area per concurrent pass
     for (hipStream_t& st : h->slot_streams) HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

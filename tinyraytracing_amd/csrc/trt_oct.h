@@ -23,11 +23,20 @@
 //      p + qlo s <= lo, p + qhi s >= hi); per axis the near plane is computed as fma(q, s inv, (p - o) inv - m) and the far plane
 //      with + m, where m = 2^-21 |(p - o) inv| + 2^-13 |s inv| + 2^-100 exceeds the rounding error of BOTH computations (ours: two
 //      roundings of the origin term, one of the fma; the reference's: (lo - o) rounded, times inv rounded; |values| <=
-//      |(p - o) inv| + 255 |s inv|; u = 2^-24: 6 u |org| + 765 u |s inv| needed, 8 u |org| + 2048 u |s inv| taken).  An axis whose
-//      reciprocal direction is not finite or beyond 2^64 (d = 0, denormal d) is left out of the test altogether (its reciprocal is
-//      replaced by NaN, which fmaxf / fminf drop): leaving a constraint out only enlarges the visited set.  Scenes whose
-//      coordinates reach 2^40 are not given this node kind (products stay finite).  So the traversal reaches a SUPERSET of the
-//      reference's leaves and never culls a node that holds a hit which counts (trt_cull_bound, trt_prims.h).
+//      |(p - o) inv| + 255 |s inv|; u = 2^-24: 6 u |org| + 765 u |s inv| needed, 8 u |org| + 2048 u |s inv| taken).  Where a product
+//      overflows the planes come out as NaN or as the infinity on their own side, and fmaxf / fminf drop NaNs: the axis then
+//      constrains nothing, which only enlarges the visited set.
+//      A direction component that is exactly zero (1 / d = +-inf: about one camera ray in 40 000 of an axis-aligned camera, where
+//      d.x is a difference of numbers near 278 and comes out as a multiple of 3e-5) gets the reference's own meaning: its slab test
+//      yields (-inf, +inf) when the origin lies between the planes (NaN, dropped, when it lies ON one) and two infinities of one sign
+//      — a miss, unless every axis is like that, and then no triangle test can hit either — when it lies outside.  Here the
+//      reciprocal of such an axis is replaced by K = 2^40 and both margins grow by 2^30 (beyond every culling bound, 2^24 at most
+//      for coordinates below 2^40): an origin between the stored planes, on them or less than 2^-10 outside gives near < 0 and
+//      far > every bound — no constraint — and one further outside |near| or |far| beyond 2^30, a miss, as in the reference.
+//      (Leaving such an axis out altogether, the first version, was exact too, but a ray along an axis then visited every node
+//      of a slab of the scene: 1 500 nodes and 4 600 triangles for the centre column of the 2 M-triangle mesh, one lane for
+//      milliseconds.)  Scenes whose coordinates reach 2^40 are not given this node kind.  So the traversal reaches a SUPERSET of
+//      the reference's leaves and never culls a node that holds a hit which counts (trt_cull_bound, trt_prims.h).
 //  (2) The extra leaves must not contribute: a hit counts only if the ray also passes the reference's test of the exact box of the
 //      triangle's own leaf — for a nested tree (the only kind that gets this node kind) equivalent to passing every box above it —
 //      and the leaf-box rule holds.  As with that rule (trt_path.h, traceClosest) the RESULT of a ray is checked once, when it is
@@ -37,6 +46,10 @@
 //      the leaf-box rule exists for.
 #pragma once
 #include "trt_path.h"
+
+#ifndef TRT_OCT_PK
+#define TRT_OCT_PK 0
+#endif
 
 namespace trtd {
 
@@ -49,11 +62,14 @@ static_assert(sizeof(OctNode) == 80, "OctNode is five 16-byte words");
 
 // Per-ray constants of the quantised-frame test.
 struct OctRay {
-    f3 o, inv;         // inv: 1 / d with the axes that take no part in the test replaced by NaN
+    f3 o, inv;         // inv: 1 / d, an infinite one (d = +-0) replaced by TRT_OCT_DEAD_K
     uint32_t octinv4;  // (7 - octant) in each of the four bytes; octant bit 2 = d.x < 0, bit 1 = d.y < 0, bit 0 = d.z < 0.  A CLEAR bit
                        // of (7 - octant) therefore says: that component of d is negative (the near plane of the axis is the box's upper one)
 };
-TRT_HD inline float octSafeInv(float inv) { return fabsf(inv) <= 1.8446744e19f ? inv : u2f(0x7FC00000u); }
+#define TRT_OCT_DEAD_K 1.099511627776e12f   /* 2^40: stands in for 1 / 0 (header, (1)) */
+#define TRT_OCT_DEAD_M 1.073741824e9f      /* 2^30: what the margins of such an axis grow by */
+// +-inf -> +K: `d < 0` is false for -0 as well, so the axis counts as a positive one and its near plane is the lower one
+TRT_HD inline float octSafeInv(float inv) { return fabsf(inv) <= 3.4028234e38f ? inv : (inv != inv ? inv : TRT_OCT_DEAD_K); }
 TRT_HD inline OctRay makeOctRay(f3 o, f3 d, f3 inv)
 {
     OctRay r;
@@ -82,9 +98,12 @@ TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, cons
     // ray in the node's frame: t(bound byte b) = b * idir + org, widened by m (header, (1))
     const float idx = u2f((ew & 0xFFu) << 23) * R.inv.x, idy = u2f(((ew >> 8) & 0xFFu) << 23) * R.inv.y, idz = u2f(((ew >> 16) & 0xFFu) << 23) * R.inv.z;
     const float ogx = (q0.x - R.o.x) * R.inv.x, ogy = (q0.y - R.o.y) * R.inv.y, ogz = (q0.z - R.o.z) * R.inv.z;
-    const float mx = fmaf(fabsf(idx), 1.220703125e-4f, fmaf(fabsf(ogx), 4.76837158203125e-7f, 7.8886090522101181e-31f));
-    const float my = fmaf(fabsf(idy), 1.220703125e-4f, fmaf(fabsf(ogy), 4.76837158203125e-7f, 7.8886090522101181e-31f));
-    const float mz = fmaf(fabsf(idz), 1.220703125e-4f, fmaf(fabsf(ogz), 4.76837158203125e-7f, 7.8886090522101181e-31f));
+    const float cx = fabsf(R.inv.x) == TRT_OCT_DEAD_K ? TRT_OCT_DEAD_M : 7.8886090522101181e-31f;  // 2^-100, or the margin of an axis with d = 0
+    const float cy = fabsf(R.inv.y) == TRT_OCT_DEAD_K ? TRT_OCT_DEAD_M : 7.8886090522101181e-31f;
+    const float cz = fabsf(R.inv.z) == TRT_OCT_DEAD_K ? TRT_OCT_DEAD_M : 7.8886090522101181e-31f;
+    const float mx = fmaf(fabsf(idx), 1.220703125e-4f, fmaf(fabsf(ogx), 4.76837158203125e-7f, cx));
+    const float my = fmaf(fabsf(idy), 1.220703125e-4f, fmaf(fabsf(ogy), 4.76837158203125e-7f, cy));
+    const float mz = fmaf(fabsf(idz), 1.220703125e-4f, fmaf(fabsf(ogz), 4.76837158203125e-7f, cz));
     const float onx = ogx - mx, ony = ogy - my, onz = ogz - mz, ofx = ogx + mx, ofy = ogy + my, ofz = ogz + mz;
     // near / far plane bytes by the sign of the direction, four children per word
     const bool nx = (R.octinv4 & 4u) == 0, ny = (R.octinv4 & 2u) == 0, nz = (R.octinv4 & 1u) == 0;
@@ -105,6 +124,27 @@ TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, cons
         const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xFFu;                  // 0xFF in the bytes of inner children
         const uint32_t pos4 = (m4 ^ (R.octinv4 & inner_mask4)) & 0x1F1F1F1Fu;   // position in the hit mask
         const uint32_t bits4 = (m4 >> 5) & 0x07070707u;                         // what to set there: 1 (inner), unary count (leaf), 0 (empty)
+#if defined(__HIP_DEVICE_COMPILE__) && TRT_OCT_PK
+        // two children per v_pk_fma_f32 (5.1 clocks per wave against 2 x 4.2 for two v_fma_f32, tools/valu_probe.hip); the same IEEE
+        // fma per element, so the hit mask is the same
+        typedef float v2f __attribute__((ext_vector_type(2)));
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int k = 0; k < 4; k += 2) {
+            const v2f tnx = __builtin_elementwise_fma(v2f{octByte(nrx[h], k), octByte(nrx[h], k + 1)}, v2f{idx, idx}, v2f{onx, onx});
+            const v2f tny = __builtin_elementwise_fma(v2f{octByte(nry[h], k), octByte(nry[h], k + 1)}, v2f{idy, idy}, v2f{ony, ony});
+            const v2f tnz = __builtin_elementwise_fma(v2f{octByte(nrz[h], k), octByte(nrz[h], k + 1)}, v2f{idz, idz}, v2f{onz, onz});
+            const v2f tfx = __builtin_elementwise_fma(v2f{octByte(frx[h], k), octByte(frx[h], k + 1)}, v2f{idx, idx}, v2f{ofx, ofx});
+            const v2f tfy = __builtin_elementwise_fma(v2f{octByte(fry[h], k), octByte(fry[h], k + 1)}, v2f{idy, idy}, v2f{ofy, ofy});
+            const v2f tfz = __builtin_elementwise_fma(v2f{octByte(frz[h], k), octByte(frz[h], k + 1)}, v2f{idz, idz}, v2f{ofz, ofz});
+            const float tmin0 = fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, 0.0f)), tmax0 = fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, cull));
+            const float tmin1 = fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, 0.0f)), tmax1 = fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, cull));
+            const uint32_t b0 = (bits4 >> (8 * k)) & 0xFFu, p0 = (pos4 >> (8 * k)) & 0xFFu, b1 = (bits4 >> (8 * k + 8)) & 0xFFu, p1 = (pos4 >> (8 * k + 8)) & 0xFFu;
+            hits |= !(tmin0 > tmax0) ? (b0 << p0) : 0u;
+            hits |= !(tmin1 > tmax1) ? (b1 << p1) : 0u;
+        }
+#else
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -117,6 +157,7 @@ TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, cons
             const uint32_t b = (bits4 >> (8 * k)) & 0xFFu, p = (pos4 >> (8 * k)) & 0xFFu;
             hits |= hit ? (b << p) : 0u;
         }
+#endif
     }
     ng.x = f2u(q1.x);
     ng.y = (hits & 0xFF000000u) | (ew >> 24);
