@@ -199,6 +199,9 @@ typedef struct trt_stats {
     uint32_t redo_rays;         /* rays whose traversal result failed the check made when it is stored (a hit in front of the box of its
                                  * own leaf, or — 8-wide nodes — on a leaf whose exact box the ray misses) and that were traced again in
                                  * the exact form: a handful per 10^7 on padded trees; a large number says the slow path is carrying the render */
+    uint64_t lane_census[4];    /* TRT_FLAG_COUNT, persistent traversal kernels: summed over every wave iteration, the lanes waiting for a node
+                                 * step [0], for a triangle step [1], holding a finished ray that waits for the refill batch [2]; [3] = the
+                                 * iterations (x 64 = lane slots; what is left held no ray) — where the idle SIMD lanes are */
 } trt_stats;
 
 typedef struct trt_handle trt_handle;

@@ -74,7 +74,7 @@ class Stats(C.Structure):
                 ("shaded_hits", C.c_uint64), ("inner_visits", C.c_uint64 * 2), ("tri_tests", C.c_uint64 * 2), ("wave_steps", C.c_uint64 * 2),
                 ("launches", C.c_uint64 * TRT_MAX_KERNELS), ("kernel_ms", C.c_double * TRT_MAX_KERNELS),
                 ("render_ms", C.c_double), ("passes", C.c_uint32), ("max_bounces", C.c_uint32),
-                ("rows_rendered", C.c_uint64), ("inner_node_bytes", C.c_uint32), ("redo_rays", C.c_uint32)]
+                ("rows_rendered", C.c_uint64), ("inner_node_bytes", C.c_uint32), ("redo_rays", C.c_uint32), ("lane_census", C.c_uint64 * 4)]
 
     @property
     def rays(self):
