@@ -12,16 +12,25 @@ Which snapshot belongs to the committed code was established by ranking all of t
   veach-mis/image10.png   matches parity mode to 1.3 % median block error, correlation 0.9992 — and NOT TRT_FLAG_FIXED_NEE
                           (23 %): the three-light bias of Q3 (every CDF draw spans light 1's area), Q4 and Q5 are in the
                           reference's own output, and the restatement reproduces them.
-  staircase/image10.png   parity 7 % at 2 spp (noise of both renders), fixed-NEE 20 %: same conclusion on six lights and
-                          three textures (texture orientation and the BGR order of pathTracing.cpp:24-25 included).
-  staircase/image256.png  parity 9 %, fixed 22 %: a converged snapshot of the same estimator.
+  staircase/image10.png   parity 7 % at 2 spp, 5.5 % at the snapshot's own 10 spp; fixed-NEE 20 %: same conclusion on six lights and
+                          three textures (texture orientation and the BGR order of pathTracing.cpp:24-25 included).  NOT all of it is
+                          noise: two renders of this estimator with different seeds at 1280x720 x 10 spp differ by 2.2 % (tools/
+                          two_seed_floor.py; veach-mis: floor 1.07 %, snapshot 1.01 % — that one sits ON its floor, mean radiance ratio
+                          1.0000), so ~3 points are systematic: this build renders staircase 7.2 % brighter in the mean (per channel
+                          1.09 / 1.06 / 1.03: the warm lights).  A least-squares fit of the snapshot by six single-light renders gives
+                          leftLight — 72 % of the image's energy, reaching the room through the glass — a weight of 0.88 and the
+                          others 0.92-1.12.  What it is NOT (each a test below): lost updates of the racy accumulation (< 5e-5 of
+                          the mass), the three identically seeded engines (+-1.7 %, the size of the 10-spp floor of the mean), a
+                          missing 1 / P_RR (that variant is 21 % too DARK on staircase).  Unexplained, bounded at 5.6 % median block error.
+  staircase/image256.png  parity 9 %, fixed 22 %: a converged snapshot of the same estimator (same residual: 5.7 % at 256 spp).
   veach-mis/image256.png  parity 61 %, fixed 36 %: an older light-selection experiment (its siblings image10-area /
                           -radiance / -avg / -num are named after them); kept as the negative control.
   test/image10.png, test/image10-0.png (`back`)   geometry and pixel grid exact (first/last lit row and column), block
                           structure correlated 0.987, but 11-22 % darker than the committed code renders this scene, the
                           ceiling (indirect light only) most: older revisions of the indirect term (without the 1 / P_RR of
                           pathTracing.cpp:84 the distance halves: test_back_snapshots_predate_...).  They pin Q1/Q2 and the
-                          geometry, not the brightness.
+                          geometry, not the brightness.  (Measured at the snapshots' 10 spp: 21.5 % / 11.3 % median block error against
+                          a two-seed floor of 1.2 %; mean radiance of this build 1.26x / 1.11x the snapshots'.)
 
 Tolerances are stated per fixture below; the CPU tests use the oracle at a few spp, the -m gpu tests the HIP render
 through the C-ABI at the snapshot's own sample count.
@@ -125,7 +134,10 @@ def test_back_snapshots_pin_pixel_grid_and_geometry(fixture):
     assert _lit_extent(T.tonemap(fixed)) != _lit_extent(png)
     med, p90, corr = _compare(img, png)
     assert corr >= 0.98, corr            # measured 0.987: same silhouettes block for block
-    assert med <= 0.30, med              # measured 0.11 (image10-0) / 0.22 (image10): an older, darker indirect term
+    # brightness: NOT pinned by these two files.  Measured 0.113 (image10-0) / 0.215 (image10) against a two-seed floor of 0.012
+    # (tools/two_seed_floor.py) — systematic, and explained by the next test (snapshots written before the 1 / P_RR of
+    # pathTracing.cpp:84 existed: without it this build is within 5.6 % of both).  The bound only says "that far and no further".
+    assert med <= {"back_image10.png": 0.26, "back_image10-0.png": 0.15}[fixture], med
 
 
 def test_back_snapshots_predate_the_russian_roulette_compensation(monkeypatch):
@@ -149,12 +161,68 @@ def test_back_snapshots_predate_the_russian_roulette_compensation(monkeypatch):
         assert med_v < 0.08 and corr_v > 0.993 and med_v < 0.7 * med_c and corr_v > corr_c, (fixture, med_c, med_v, corr_c, corr_v)
 
 
+# ---- what the one-sided brightness residual is NOT: the two things the parity path does not take from the reference
+EXPERIMENT_CASES = [("back", 256, 256), ("veach-mis", 320, 180), ("staircase", 320, 180)]
+
+
+@pytest.mark.parametrize("name,w,h", EXPERIMENT_CASES, ids=[c[0] for c in EXPERIMENT_CASES])
+def test_lost_updates_of_the_racy_accumulation_are_negligible(name, w, h):
+    """Hypothesis (i): the reference adds color / SAMPLE into one shared `double image` from all its OpenMP threads without synchronisation
+    (main.cpp:79-81,103-108: the team runs over the SAMPLE index, every thread sweeps the whole image), so overwritten updates could make
+    its renders darker.  oracle_render_literal_experiment(ORACLE_EXP_RACY_ACCUM) does exactly that — a real data race, 8 threads in
+    lock-step from pixel (0, 0) — with the per-sample counter streams, so the race-free sum is oracle_render_literal's image and the
+    difference is the lost mass.  Measured here: 4.9e-5 (back), 7.6e-8 (veach-mis), 0 (staircase) of the image's energy, in 0-3 pixels
+    — four orders of magnitude below back's 11-26 % and staircase's 7 %.  (A pixel's read-modify-write is three instructions; the
+    path between two of them takes microseconds, and the threads drift apart within the first rows.)"""
+    s = get_scene(name, w, h)
+    p = T.make_params(w, h, 10, 12345)
+    clean = O.render_literal(s.flat, p)[0].astype(np.float64)
+    racy = O.render_literal_experiment(s.flat, p, O.EXP_RACY_ACCUM, threads=8).astype(np.float64)
+    lost = (clean.sum() - racy.sum()) / clean.sum()
+    assert -1e-6 <= lost <= 1e-3, lost
+
+
+@pytest.mark.parametrize("name,w,h", EXPERIMENT_CASES, ids=[c[0] for c in EXPERIMENT_CASES])
+def test_identically_seeded_engines_do_not_shift_the_brightness(name, w, h):
+    """Hypothesis (ii): shade(), Sample() and nextRay() each own a static default_random_engine seeded with time(NULL) at its first call
+    (pathTracing.cpp:33,113,149) — the same second, so the three produce IDENTICAL streams (light-point weights, lobe choice and
+    direction angles are then correlated), RR()'s is default-seeded and main()'s was seeded before the scene was loaded.
+    ORACLE_EXP_SHARED_ENGINES renders with five mt19937 engines (MSVC's default_random_engine) seeded that way, in the reference's
+    loop order; ORACLE_EXP_INDEPENDENT_ENGINES is the control with three different seeds.  Mean radiance shared / independent,
+    measured: 1.011 (back), 0.983 (veach-mis), 0.998 (staircase) — inside the spread two independent 10-spp renders of these sizes
+    show, and on veach-mis, where this build matches the reference's snapshot to 1.0000 in the mean, in the direction that would
+    spoil the match.  Not the cause of a one-sided 7-26 %."""
+    s = get_scene(name, w, h)
+    p = T.make_params(w, h, 10, 12345)
+    shared = O.render_literal_experiment(s.flat, p, O.EXP_SHARED_ENGINES).astype(np.float64)
+    indep = O.render_literal_experiment(s.flat, p, O.EXP_INDEPENDENT_ENGINES).astype(np.float64)
+    counter = O.render_literal(s.flat, p)[0].astype(np.float64)
+    r = shared.mean() / indep.mean()
+    assert abs(r - 1.0) <= 0.035, r
+    assert abs(indep.mean() / counter.mean() - 1.0) <= 0.035  # the control: another generator, the same picture
+
+
+def test_staircase_snapshots_have_the_russian_roulette_compensation():
+    """... and hypothesis (iii), the one that does explain `back` (next to this test's sibling above): on staircase the estimator WITHOUT
+    1 / P_RR is 21 % too dark against image10.png (mean 0.79 of the snapshot's; the committed one 1.07) — the staircase snapshots were
+    written by the committed indirect term, so their 7 % are something else (see the header of this file)."""
+    png = _png("staircase_image10.png")
+    s = get_scene("staircase", 640, 360)
+    p = T.make_params(640, 360, 6, SEEDS["staircase"])
+    committed = O.render(s.flat, p)[0]
+    variant = O.render(s.flat, p, mode=O.MODE_ITERATIVE | O.MODE_EXPERIMENT_NO_RR_DIV)[0]
+    ref_mean = _lin8(png).mean()
+    r_c, r_v = _lin8(T.tonemap(committed)).mean() / ref_mean, _lin8(T.tonemap(variant)).mean() / ref_mean
+    assert 1.0 <= r_c <= 1.15, r_c      # measured 1.07 at full size
+    assert r_v <= 0.88, r_v             # measured 0.79
+
+
 # ------------------------------------------------------------------------------------------------ HIP path
 # fixture -> (samples per pixel of the snapshot = what the HIP render uses, max median block error, max p90, min correlation)
 GPU_BOUNDS = {
     "veach-mis_image10.png": (10, 0.02, 0.07, 0.998),      # measured 0.0105, 0.045, 0.9994
-    "staircase_image10.png": (10, 0.075, 0.25, 0.975),     # measured 0.056, 0.194, 0.985 (two 10-spp renders of a high-variance scene)
-    "staircase_image256.png": (256, 0.075, 0.25, 0.975),   # measured 0.057, 0.199, 0.987
+    "staircase_image10.png": (10, 0.065, 0.25, 0.975),     # measured 0.055, 0.194, 0.985: a two-seed floor of 0.022 + 0.033 systematic (file header)
+    "staircase_image256.png": (256, 0.065, 0.25, 0.975),   # measured 0.057, 0.199, 0.987: the same residual, converged
 }
 
 

@@ -660,7 +660,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     }
     const size_t rows_bytes = (rows.size() * sizeof(int32_t) + 255) & ~(size_t)255;
     const size_t counts_bytes = (size_t)COUNT_STRIDE * COUNT_ROW * sizeof(uint32_t);
-    const size_t stats_bytes = 512;  // DeviceStats (128 B), then per pass slot 128 B: the redo counters (2 words) and the oct driver's queue counters (16 words at +32 B)
+    const size_t stats_bytes = 768;  // DeviceStats (128 B), then per pass slot 256 B: the redo counters (2 words) and the oct driver's queue counters (TRT_OCT_QUEUES + 1 words at +32 B)
+    static_assert(32 + (TRT_OCT_QUEUES + 1) * 4 <= 256, "queue counters do not fit their slot");
     const size_t acc_bytes = (size_t)npix * 3 * sizeof(double);
     if (int e = h->small_buf.ensure(rows_bytes + counts_bytes * N_SLOTS + stats_bytes + acc_bytes)) return e;
     char* sb = (char*)h->small_buf.p;
@@ -682,8 +683,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         for (uint32_t l = 0; l < (uint32_t)TRT_MAX_LIGHTS; ++l) S.SQ[l] = ShadowQueue{nullptr, nullptr, nullptr};
         for (uint32_t l = 0; l < nl; ++l) { S.SQ[l].sa = take(); S.SQ[l].sb = take(); S.SQ[l].sw = take(); }
         S.redo.idx = (uint32_t*)base;  // N indices behind the queues
-        S.redo.count = d_redo + 32 * k;
-        S.redo.qctl = d_redo + 32 * k + 8;
+        S.redo.count = d_redo + 64 * k;
+        S.redo.qctl = d_redo + 64 * k + 8;
         S.d_counts = (uint32_t*)(sb + rows_bytes + counts_bytes * (size_t)k);
         S.host_counts = h->pinned_counts + (size_t)k * (2 * COUNT_ROW + 16);
         S.seq = h->slot_seq[k];
@@ -987,7 +988,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     const uint32_t n32 = (uint32_t)n;
     const size_t in_bytes = (size_t)n * 3 * sizeof(float);
     const size_t q16 = (size_t)n * sizeof(f4);
-    if (int e = h->io_buf.ensure(2 * in_bytes + 3 * q16 + 256 + 512 + (size_t)n * sizeof(uint32_t))) return e;  // + statistics, counters, redo list
+    if (int e = h->io_buf.ensure(2 * in_bytes + 3 * q16 + 256 + 768 + (size_t)n * sizeof(uint32_t))) return e;  // + statistics, counters, redo list
     char* b = (char*)h->io_buf.p;
     f4* ra = (f4*)b;
     f4* rb = ra + n;
@@ -998,11 +999,11 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     d_stats = (DeviceStats*)(((uintptr_t)d_stats + 15) & ~(uintptr_t)15);
     RedoList redo;  // rays for k_trace_fix (trt_kernels.h): the counter sits behind the statistics, the list behind it
     redo.count = (uint32_t*)((char*)d_stats + 128);
-    redo.qctl = (uint32_t*)((char*)d_stats + 160);  // 16 words
-    redo.idx = (uint32_t*)((char*)d_stats + 512);
+    redo.qctl = (uint32_t*)((char*)d_stats + 160);  // TRT_OCT_QUEUES + 1 words
+    redo.idx = (uint32_t*)((char*)d_stats + 768);
     HIPC(hipMemcpy(d_org, org, in_bytes, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_dir, dir, in_bytes, hipMemcpyHostToDevice));
-    HIPC(hipMemset(d_stats, 0, 512));
+    HIPC(hipMemset(d_stats, 0, 768));
     hipLaunchKernelGGL(k_pack_rays, dim3(std::min<uint32_t>((n32 + 255) / 256, 65536u)), dim3(256), 0, nullptr, d_org, d_dir, ra, rb, n32);
     struct Events {  // destroyed on every path out of this function
         hipEvent_t e0 = nullptr, e1 = nullptr;

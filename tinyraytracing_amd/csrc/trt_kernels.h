@@ -193,7 +193,7 @@ __device__ __forceinline__ void fetchRay(const SceneDev& sc, const RaySource& sr
 struct RedoList {
     uint32_t* count;
     uint32_t* idx;
-    uint32_t* qctl;  // the oct driver's queue counters (traceQueuePersistentOct): 16 words, zero between launches
+    uint32_t* qctl;  // the oct driver's queue counters (traceQueuePersistentOct): TRT_OCT_QUEUES + 1 words, zero between launches
 };
 
 constexpr uint32_t TRT_REF_IDLE = 0xFFFFFFFFu;  // lane holds no ray        } both have the leaf bit set and
@@ -526,14 +526,16 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
 // What is different from the 4-wide driver is where rays come from and where results go (lane census of round 3,
 // profiles/r03_lane_census.txt: with static per-wave slices and results stored by the lane that traced them, 20-25 % of the lane
 // slots held a finished ray waiting for the refill batch and 8-30 % nothing at all, at the end of every slice):
-//  * rays are fetched from the launch's queue by atomic counters, one per XCD (each owns an eighth of the queue, so neighbours in the
-//    queue still meet in one L2; a wave that finds its XCD's share taken goes on with the next one): no wave runs out of rays before
-//    the launch does;
+//  * rays are fetched from the launch's queue in chunks, by atomic counters (32 shares of the queue, a wave starts on those of its
+//    XCD's eighth so that neighbours in the queue still meet in one L2, and goes on with the next share when one is taken): no wave
+//    runs out of rays before the launch does.  (One atomic per BATCH was 10x slower than static slices: device-scope atomics on one
+//    address are served at ~5 M/s whichever XCD they come from.)
 //  * a finished ray is PARKED — (queue index, t, triangle, flags) into a per-wave LDS buffer — and its lane is free at once; the
 //    expensive part of a result (the check against the exact box of its leaf, the winner's barycentrics, the store) runs when 64 results
 //    are parked, with every lane busy, on the ray re-read from the queue.  Refills therefore cost a ray fetch and three reciprocals
 //    only, and can be made for small batches (sc.refill_min).
-// idx == ~0: the lane holds no ray.  RedoList::qctl: [0..7] the XCD counters, [8] blocks that are through (the last one resets all).
+// idx == ~0: the lane holds no ray.  RedoList::qctl: the TRT_OCT_QUEUES share counters, then the blocks that are through (the last one resets all).
+constexpr int TRT_OCT_QUEUES = 32;  // shares of a launch's queue (a counter each in RedoList::qctl, then the count of finished blocks)
 constexpr int TRT_PARK = 128;  // parked results per wave (16 B each): 64 waiting for a full flush + up to 64 arriving in one iteration
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
 __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
@@ -549,9 +551,15 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     const unsigned long long lower = (1ull << lane) - 1ull;
     f4* const park = reinterpret_cast<f4*>(smem + 2 * DEPTH * TRT_TRACE_BLOCK) + (threadIdx.x >> 6) * TRT_PARK;  // this wave's parked results
     uint32_t n_park = 0;  // wave-uniform
-    // this wave's share of the queue: XCD x (blocks are dealt to the XCDs round-robin) owns [n x / 8, n (x + 1) / 8)
-    uint32_t cur_q = blockIdx.x & 7u, tried = 0;
+    // The launch's queue is cut into TRT_OCT_QUEUES shares with a counter each; a wave takes CHUNKS of a share (one atomic per chunk,
+    // not per batch) and refills its lanes from its chunk.  XCD x (blocks are dealt to the XCDs round-robin) starts on the shares of its
+    // own eighth of the queue, so that neighbours in the queue still meet in one L2.
+    uint32_t cur_q = (blockIdx.x & 7u) * (TRT_OCT_QUEUES / 8) + ((blockIdx.x >> 3) & (TRT_OCT_QUEUES / 8 - 1)), tried = 0;
     bool exhausted = n == 0u;
+    uint32_t c_next = 0, c_end = 0;  // the wave's current chunk (wave-uniform)
+    // chunk: about eight per wave and launch, between one batch and sixteen
+    uint32_t chunk = (n / (gridDim.x * (TRT_TRACE_BLOCK / 64) * 8u) + 63u) & ~63u;
+    chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
 
     constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
     uint32_t idx = NO_RAY;
@@ -593,26 +601,30 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
             n_park += n_fin;
             if (n_park >= 64u) { flush(n_park - 64u, 64u); n_park -= 64u; }
         }
-        // ---- free lanes take rays from the launch's queue, a batch at a time
+        // ---- free lanes take rays from the wave's chunk, a batch at a time; an empty chunk is replaced from the launch's queue
         const unsigned long long m_work = ballotb(working);
         const unsigned long long m_free = ~m_work;
         if (!exhausted && (m_work == 0ull || (uint32_t)__popcll(m_free) >= sc.refill_min)) {
-            const uint32_t cnt = (uint32_t)__popcll(m_free);
-            const uint32_t q0 = (uint32_t)(((unsigned long long)n * cur_q) >> 3), q1 = (uint32_t)(((unsigned long long)n * (cur_q + 1u)) >> 3);
-            uint32_t base = 0;
-            if (lane == 0) {
-                // a look before the atomic: at the end of a launch every wave finds every share taken, and same-address atomics serialise
-                base = __hip_atomic_load(redo.qctl + cur_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (base < q1 - q0) base = atomicAdd(redo.qctl + cur_q, cnt);
+            if (c_next == c_end) {
+                const uint32_t q0 = (uint32_t)(((unsigned long long)n * cur_q) / TRT_OCT_QUEUES), q1 = (uint32_t)(((unsigned long long)n * (cur_q + 1u)) / TRT_OCT_QUEUES);
+                uint32_t base = 0;
+                if (lane == 0) {
+                    // a look before the atomic: at the end of a launch every wave finds every share taken, and atomics on one address
+                    // from all over the chip are served one after the other (~0.2 us each: measured, profiles/r03_ab_oct.txt)
+                    base = __hip_atomic_load(redo.qctl + cur_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (base < q1 - q0) base = atomicAdd(redo.qctl + cur_q, chunk);
+                }
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= q1 - q0) {  // this share is taken: on to the next one (shares only ever run dry, so TRT_OCT_QUEUES misses end it)
+                    cur_q = cur_q + 1u == (uint32_t)TRT_OCT_QUEUES ? 0u : cur_q + 1u;
+                    if (++tried == (uint32_t)TRT_OCT_QUEUES) exhausted = true;
+                    continue;
+                }
+                c_next = q0 + base;
+                c_end = (q1 - q0) - base < chunk ? q1 : c_next + chunk;
             }
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base >= q1 - q0) {  // this share is taken: on to the next XCD's (shares only ever run dry, so eight misses end it)
-                cur_q = (cur_q + 1u) & 7u;
-                if (++tried == 8u) exhausted = true;
-                continue;
-            }
-            const uint32_t i = q0 + base + (uint32_t)__popcll(m_free & lower);
-            if (!working && i < q1) {
+            const uint32_t i = c_next + (uint32_t)__popcll(m_free & lower);
+            if (!working && i < c_end) {
                 idx = i;
                 f4 a, b;
                 fetchRay<PRIMARY>(sc, src, idx, a, b);
@@ -623,6 +635,8 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
                 ng.x = 0u; ng.y = 0x80000000u;  // the root
                 tg.y = 0u;
             }
+            const uint32_t taken = (uint32_t)__popcll(m_free);
+            c_next = (c_end - c_next) < taken ? c_end : c_next + taken;
         }
         const bool is_leaf = tg.y != 0u;
         const bool is_inner = !is_leaf && (ng.y & 0xFF000000u) != 0u;
@@ -678,8 +692,8 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(redo.qctl + 8, 1u) + 1u == gridDim.x) {
-            for (int k = 0; k < 9; ++k) redo.qctl[k] = 0u;
+        if (atomicAdd(redo.qctl + TRT_OCT_QUEUES, 1u) + 1u == gridDim.x) {
+            for (int k = 0; k <= TRT_OCT_QUEUES; ++k) redo.qctl[k] = 0u;
         }
     }
 }

@@ -33,13 +33,11 @@ scene_args() {
 for sc in veach stair soup blob2m; do
   a=$(scene_args $sc)
   run ${sc}_default "TRT_NODE_KIND=1" $a
-  for rf in 8 16 24 32 48; do run ${sc}_refill$rf "TRT_NODE_KIND=1 TRT_REFILL_MIN=$rf" $a; done
+  for rf in 16 24 32; do run ${sc}_refill$rf "TRT_NODE_KIND=1 TRT_REFILL_MIN=$rf" $a; done
 done
 for sc in veach stair; do
   a=$(scene_args $sc)
-  for ob in 1024 1536 2048; do run ${sc}_blocks$ob "TRT_NODE_KIND=1 TRT_OCT_BLOCKS=$ob TRT_REFILL_MIN=16" $a; done
-  for w in 2:3 1:2; do run ${sc}_sched$w "TRT_NODE_KIND=1 TRT_SCHED_W=$w TRT_REFILL_MIN=16" $a; done
+  for ob in 1024 1536; do run ${sc}_blocks$ob "TRT_NODE_KIND=1 TRT_OCT_BLOCKS=$ob" $a; done
 done
 run blob10m_default "TRT_NODE_KIND=1" $(scene_args blob10m)
-run blob10m_refill16 "TRT_NODE_KIND=1 TRT_REFILL_MIN=16" $(scene_args blob10m)
 CENSUS_REFILLS=default,16 timeout -k 10 300 python tools/lane_census.py veach-mis:64 staircase:32 soup:16 blob:32 2>&1 | grep -v amdgpu.ids
