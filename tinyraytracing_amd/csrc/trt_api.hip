@@ -112,14 +112,6 @@ struct trt_handle {
         b = std::min(std::max(b, 8u), std::min(max_blocks, 8192u));
         return (b + 7u) & ~7u;  // multiple of 8 for the XCD swizzle; <= MAX_TRACE_BLOCKS (8192) since that is one too
     }
-    // The oct kernels fetch their rays from the launch's queue on demand (trt_kernels.h): the grid is what the chip holds at once —
-    // 28 KiB of LDS per block: five blocks per CU — never more blocks than there are batches of 256 rays.
-    uint32_t oct_blocks = 256 * 5;
-    uint32_t octGrid(uint32_t n) const
-    {
-        const uint32_t b = std::min((n + TRT_TRACE_BLOCK - 1) / TRT_TRACE_BLOCK, oct_blocks);
-        return (std::max(b, 8u) + 7u) & ~7u;  // a multiple of 8: one share of the queue per XCD
-    }
     uint32_t tail_n = 131072;  // queue length at or below which k_tail finishes the pass (TRT_TAIL_N overrides)
     DevBuf arena, spill, small_buf, out_buf, io_buf;
     size_t spill_words_per_slot = 0;
@@ -317,7 +309,7 @@ constexpr uint32_t OCT_LDS_LEVELS = 10;
 template <bool COUNT, bool PRIMARY>
 void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats, RedoList redo)
 {
-    const dim3 g(h->node_kind == 1 && h->trace_impl != 0 ? h->octGrid(n) : h->traceGrid(n)), b(TRT_TRACE_BLOCK);
+    const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->trace_impl == 0) { TRT_LAUNCH_CLOSEST(1, false, 0, 0); return; }
     if (h->node_kind == 1) TRT_BY_OCT_DEPTH(TRT_LAUNCH_CLOSEST);
     else TRT_BY_DEPTH(TRT_LAUNCH_CLOSEST, 3, 0);
@@ -327,7 +319,7 @@ void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill
 template <bool COUNT>
 void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any, RedoList redo)
 {
-    const dim3 g(h->node_kind == 1 && h->trace_impl != 0 ? h->octGrid(n) : h->traceGrid(n)), b(TRT_TRACE_BLOCK);
+    const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->trace_impl == 0) { TRT_LAUNCH_SHADOW(1, false, 0, 0); return; }
     if (h->node_kind == 1) TRT_BY_OCT_DEPTH(TRT_LAUNCH_SHADOW);
     else TRT_BY_DEPTH(TRT_LAUNCH_SHADOW, 3, 0);
@@ -403,7 +395,6 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     if (const char* e = std::getenv("TRT_TRACE_RPW")) h->rays_per_wave = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TRT_TRACE_FILLB")) h->fill_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TRT_TRACE_MAXB")) h->max_blocks = std::max(8u, (uint32_t)std::strtoul(e, nullptr, 10));
-    if (const char* e = std::getenv("TRT_OCT_BLOCKS")) h->oct_blocks = std::max(8u, (uint32_t)std::strtoul(e, nullptr, 10));
     // shallow trees (everything L1-resident, a dozen steps per ray): the static driver has the least overhead;
     // deeper ones gain more from lane refill and step scheduling (measured: DESIGN.md)
     // the wave-uniform walk needs a 32-bit reach mask, and it evaluates the nodes in index order: every inner child must
@@ -589,7 +580,7 @@ struct PassSlot {
     uint32_t* host_counts = nullptr;  // pinned, device-visible: 2 * COUNT_ROW counters + the sequence word
     uint32_t seq = 0;                 // last sequence number asked for
     uint32_t* spill = nullptr;
-    RedoList redo{nullptr, nullptr, nullptr};  // rays the traversal kernels hand to k_trace_fix, and the oct driver's queue counters (trt_kernels.h)
+    RedoList redo{nullptr, nullptr};  // rays the traversal kernels hand to k_trace_fix (trt_kernels.h)
     enum State { IDLE, ISSUE, WAIT, RESOLVE } state = IDLE;
     uint32_t chunk = 0, s0 = 0, sc_count = 0, n_active = 0, b = 0;
     int cur = 0;
@@ -660,8 +651,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     }
     const size_t rows_bytes = (rows.size() * sizeof(int32_t) + 255) & ~(size_t)255;
     const size_t counts_bytes = (size_t)COUNT_STRIDE * COUNT_ROW * sizeof(uint32_t);
-    const size_t stats_bytes = 768;  // DeviceStats (128 B), then per pass slot 256 B: the redo counters (2 words) and the oct driver's queue counters (TRT_OCT_QUEUES + 1 words at +32 B)
-    static_assert(32 + (TRT_OCT_QUEUES + 1) * 4 <= 256, "queue counters do not fit their slot");
+    const size_t stats_bytes = 256;  // DeviceStats (128 B), then the redo counters of the pass slots (two words each)
     const size_t acc_bytes = (size_t)npix * 3 * sizeof(double);
     if (int e = h->small_buf.ensure(rows_bytes + counts_bytes * N_SLOTS + stats_bytes + acc_bytes)) return e;
     char* sb = (char*)h->small_buf.p;
@@ -683,8 +673,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         for (uint32_t l = 0; l < (uint32_t)TRT_MAX_LIGHTS; ++l) S.SQ[l] = ShadowQueue{nullptr, nullptr, nullptr};
         for (uint32_t l = 0; l < nl; ++l) { S.SQ[l].sa = take(); S.SQ[l].sb = take(); S.SQ[l].sw = take(); }
         S.redo.idx = (uint32_t*)base;  // N indices behind the queues
-        S.redo.count = d_redo + 64 * k;
-        S.redo.qctl = d_redo + 64 * k + 8;
+        S.redo.count = d_redo + 2 * k;
         S.d_counts = (uint32_t*)(sb + rows_bytes + counts_bytes * (size_t)k);
         S.host_counts = h->pinned_counts + (size_t)k * (2 * COUNT_ROW + 16);
         S.seq = h->slot_seq[k];
@@ -988,7 +977,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     const uint32_t n32 = (uint32_t)n;
     const size_t in_bytes = (size_t)n * 3 * sizeof(float);
     const size_t q16 = (size_t)n * sizeof(f4);
-    if (int e = h->io_buf.ensure(2 * in_bytes + 3 * q16 + 256 + 768 + (size_t)n * sizeof(uint32_t))) return e;  // + statistics, counters, redo list
+    if (int e = h->io_buf.ensure(2 * in_bytes + 3 * q16 + 256 + 256 + (size_t)n * sizeof(uint32_t))) return e;  // + statistics, counters, redo list
     char* b = (char*)h->io_buf.p;
     f4* ra = (f4*)b;
     f4* rb = ra + n;
@@ -999,11 +988,10 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
     d_stats = (DeviceStats*)(((uintptr_t)d_stats + 15) & ~(uintptr_t)15);
     RedoList redo;  // rays for k_trace_fix (trt_kernels.h): the counter sits behind the statistics, the list behind it
     redo.count = (uint32_t*)((char*)d_stats + 128);
-    redo.qctl = (uint32_t*)((char*)d_stats + 160);  // TRT_OCT_QUEUES + 1 words
-    redo.idx = (uint32_t*)((char*)d_stats + 768);
+    redo.idx = (uint32_t*)((char*)d_stats + 256);
     HIPC(hipMemcpy(d_org, org, in_bytes, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_dir, dir, in_bytes, hipMemcpyHostToDevice));
-    HIPC(hipMemset(d_stats, 0, 768));
+    HIPC(hipMemset(d_stats, 0, 256));
     hipLaunchKernelGGL(k_pack_rays, dim3(std::min<uint32_t>((n32 + 255) / 256, 65536u)), dim3(256), 0, nullptr, d_org, d_dir, ra, rb, n32);
     struct Events {  // destroyed on every path out of this function
         hipEvent_t e0 = nullptr, e1 = nullptr;

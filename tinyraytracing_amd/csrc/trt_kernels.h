@@ -193,7 +193,6 @@ __device__ __forceinline__ void fetchRay(const SceneDev& sc, const RaySource& sr
 struct RedoList {
     uint32_t* count;
     uint32_t* idx;
-    uint32_t* qctl;  // the oct driver's queue counters (traceQueuePersistentOct): TRT_OCT_QUEUES + 1 words, zero between launches
 };
 
 constexpr uint32_t TRT_REF_IDLE = 0xFFFFFFFFu;  // lane holds no ray        } both have the leaf bit set and
@@ -519,24 +518,18 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
     }
 }
 
-// Persistent waves over the 8-wide compressed nodes (NK = 1, trt_oct.h).  Lane state: the node group it is descending (`ng`:
-// first-child index, hit byte, imask), the triangles it still has to test (`tg`: first record, one bit each), an 8-byte stack entry
-// per level.  A lane with triangle bits waits for a leaf step, one without them for a node step; a wave runs the kind more of its
-// lanes wait for (same weights as the 4-wide driver).
-// What is different from the 4-wide driver is where rays come from and where results go (lane census of round 3,
-// profiles/r03_lane_census.txt: with static per-wave slices and results stored by the lane that traced them, 20-25 % of the lane
-// slots held a finished ray waiting for the refill batch and 8-30 % nothing at all, at the end of every slice):
-//  * rays are fetched from the launch's queue in chunks, by atomic counters (32 shares of the queue, a wave starts on those of its
-//    XCD's eighth so that neighbours in the queue still meet in one L2, and goes on with the next share when one is taken): no wave
-//    runs out of rays before the launch does.  (One atomic per BATCH was 10x slower than static slices: device-scope atomics on one
-//    address are served at ~5 M/s whichever XCD they come from.)
-//  * a finished ray is PARKED — (queue index, t, triangle, flags) into a per-wave LDS buffer — and its lane is free at once; the
-//    expensive part of a result (the check against the exact box of its leaf, the winner's barycentrics, the store) runs when 64 results
-//    are parked, with every lane busy, on the ray re-read from the queue.  Refills therefore cost a ray fetch and three reciprocals
-//    only, and can be made for small batches (sc.refill_min).
-// idx == ~0: the lane holds no ray.  RedoList::qctl: the TRT_OCT_QUEUES share counters, then the blocks that are through (the last one resets all).
-constexpr int TRT_OCT_QUEUES = 32;  // shares of a launch's queue (a counter each in RedoList::qctl, then the count of finished blocks)
-constexpr int TRT_PARK = 128;  // parked results per wave (16 B each): 64 waiting for a full flush + up to 64 arriving in one iteration
+// The same persistent-wave scheduler over the 8-wide compressed nodes (NK = 1, trt_oct.h).  Lane state: the node group it is
+// descending (`ng`: first-child index, hit byte, imask), the triangles it still has to test (`tg`: first record, one bit each), an
+// 8-byte stack entry per level.  A lane with triangle bits waits for a leaf step, one without them for a node step; a wave runs the
+// kind more of its lanes wait for (same weights).  idx == ~0: the lane holds no ray; no work bits and idx != ~0: ray finished, not
+// stored yet.  Results are checked when they are stored (checkedStore<.., OCT>): the ray must pass the exact box of its hit's leaf.
+// (Round 3 also tried rays fetched from the launch's queue through atomic counters, in chunks, with finished rays parked in LDS and
+// stored 64 at a time: lanes per step 0.55 / 0.45 -> 0.64 / 0.57, and 20-30 % SLOWER on every scene — 28 KiB of LDS and 84 VGPRs
+// leave five waves per SIMD instead of seven, and these kernels live on the texture addresser's lane-load rate, not on VALU
+// issue: profiles/r03_ab_oct.txt.  Static slices stay.)
+#ifndef TRT_OCT_LEAF_LOOP
+#define TRT_OCT_LEAF_LOOP 1
+#endif
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
 __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
@@ -549,20 +542,15 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     const bool any = SHADOW && any_flag;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lower = (1ull << lane) - 1ull;
-    f4* const park = reinterpret_cast<f4*>(smem + 2 * DEPTH * TRT_TRACE_BLOCK) + (threadIdx.x >> 6) * TRT_PARK;  // this wave's parked results
-    uint32_t n_park = 0;  // wave-uniform
-    // The launch's queue is cut into TRT_OCT_QUEUES shares with a counter each; a wave takes CHUNKS of a share (one atomic per chunk,
-    // not per batch) and refills its lanes from its chunk.  XCD x (blocks are dealt to the XCDs round-robin) starts on the shares of its
-    // own eighth of the queue, so that neighbours in the queue still meet in one L2.
-    uint32_t cur_q = (blockIdx.x & 7u) * (TRT_OCT_QUEUES / 8) + ((blockIdx.x >> 3) & (TRT_OCT_QUEUES / 8 - 1)), tried = 0;
-    bool exhausted = n == 0u;
-    uint32_t c_next = 0, c_end = 0;  // the wave's current chunk (wave-uniform)
-    // chunk: about eight per wave and launch, between one batch and sixteen
-    uint32_t chunk = (n / (gridDim.x * (TRT_TRACE_BLOCK / 64) * 8u) + 63u) & ~63u;
-    chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+    const uint32_t n_waves = gridDim.x * (TRT_TRACE_BLOCK / 64);
+    const uint32_t wave = xcdSwizzle(blockIdx.x, gridDim.x) * (TRT_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t per = (n + n_waves - 1) / n_waves;
+    const unsigned long long w0 = (unsigned long long)wave * per;
+    uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w0 < n ? w0 : n));
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)((w0 + per) < n ? (w0 + per) : n));
 
     constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
-    uint32_t idx = NO_RAY;
+    uint32_t idx = NO_RAY, pid = 0;
     int sp = 0;
     OctGroup ng, tg;
     ng.x = 0u; ng.y = 0u; tg.x = 0u; tg.y = 0u;
@@ -574,78 +562,46 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     uint32_t best_flags = 0;
     TraceProbe pr;
 
-    // the results parked in [first, first + count) -> checked (leaf box of the hit: checkedStore<.., OCT>) and stored, one per lane
-    auto flush = [&](uint32_t first, uint32_t count) {
-        if (lane < count) {
-            const f4 e = park[first + lane];
-            const uint32_t i = f2u(e.x);
-            f4 a, b;
-            fetchRay<PRIMARY>(sc, src, i, a, b);
-            const f3 fo = mk3(a.x, a.y, a.z), fd = mk3(a.w, b.x, b.y);
-            const f3 inv = mk3(1.0f / fd.x, 1.0f / fd.y, 1.0f / fd.z);
-            if (checkedStore<SHADOW, true>(sc, fo, fd, inv, e.y, (int32_t)f2u(e.z), f2u(e.w), i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any)) redo.idx[atomicAdd(redo.count, 1u)] = i;
-        }
-    };
-
     for (;;) {
-        // ---- finished rays are parked at once; 64 parked results are written out together
         const bool working = (tg.y | (ng.y & 0xFF000000u)) != 0u;
-        const bool fin = !working && idx != NO_RAY;
-        const unsigned long long m_fin = ballotb(fin);
-        if (m_fin != 0ull) {
-            const uint32_t n_fin = (uint32_t)__popcll(m_fin);
-            if (fin) {  // n_park < 64 here (flushed below at 64) and at most 64 lanes finish: TRT_PARK = 128 entries suffice
-                park[n_park + (uint32_t)__popcll(m_fin & lower)] = mk4(u2f(idx), best_t, u2f((uint32_t)best_tri), u2f(best_flags));
+        const bool done = !working && idx != NO_RAY;
+        const unsigned long long m_work = ballotb(working);
+        const unsigned long long m_done = ballotb(done);
+        const unsigned long long m_free = ~m_work;
+        const bool can_fill = next < end;
+        if (m_work == 0ull || (m_done != 0ull && (uint32_t)__popcll(can_fill ? m_free : m_done) >= sc.refill_min)) {
+            if (done) {
+                const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // the exact reciprocals (R.inv has NaN on the axes the node test leaves out)
+                if (checkedStore<SHADOW, true>(sc, R.o, d, inv, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc, any)) redo.idx[atomicAdd(redo.count, 1u)] = idx;
                 idx = NO_RAY;
             }
-            n_park += n_fin;
-            if (n_park >= 64u) { flush(n_park - 64u, 64u); n_park -= 64u; }
-        }
-        // ---- free lanes take rays from the wave's chunk, a batch at a time; an empty chunk is replaced from the launch's queue
-        const unsigned long long m_work = ballotb(working);
-        const unsigned long long m_free = ~m_work;
-        if (!exhausted && (m_work == 0ull || (uint32_t)__popcll(m_free) >= sc.refill_min)) {
-            if (c_next == c_end) {
-                const uint32_t q0 = (uint32_t)(((unsigned long long)n * cur_q) / TRT_OCT_QUEUES), q1 = (uint32_t)(((unsigned long long)n * (cur_q + 1u)) / TRT_OCT_QUEUES);
-                uint32_t base = 0;
-                if (lane == 0) {
-                    // a look before the atomic: at the end of a launch every wave finds every share taken, and atomics on one address
-                    // from all over the chip are served one after the other (~0.2 us each: measured, profiles/r03_ab_oct.txt)
-                    base = __hip_atomic_load(redo.qctl + cur_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (base < q1 - q0) base = atomicAdd(redo.qctl + cur_q, chunk);
+            if (can_fill) {
+                const uint32_t rank = (uint32_t)__popcll(m_free & lower);
+                if (!working && next + rank < end) {
+                    idx = next + rank;
+                    f4 a, b;
+                    fetchRay<PRIMARY>(sc, src, idx, a, b);
+                    d = mk3(a.w, b.x, b.y);
+                    if (SHADOW) pid = f2u(b.z);
+                    R = makeOctRay(mk3(a.x, a.y, a.z), d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));
+                    best_t = SHADOW ? b.w : TRT_INF; best_tri = -1; best_flags = 0u;
+                    sp = 0;
+                    ng.x = 0u; ng.y = 0x80000000u;  // the root
+                    tg.y = 0u;
                 }
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base >= q1 - q0) {  // this share is taken: on to the next one (shares only ever run dry, so TRT_OCT_QUEUES misses end it)
-                    cur_q = cur_q + 1u == (uint32_t)TRT_OCT_QUEUES ? 0u : cur_q + 1u;
-                    if (++tried == (uint32_t)TRT_OCT_QUEUES) exhausted = true;
-                    continue;
-                }
-                c_next = q0 + base;
-                c_end = (q1 - q0) - base < chunk ? q1 : c_next + chunk;
+                const uint32_t taken = (uint32_t)__popcll(m_free);
+                next = (end - next) < taken ? end : next + taken;
             }
-            const uint32_t i = c_next + (uint32_t)__popcll(m_free & lower);
-            if (!working && i < c_end) {
-                idx = i;
-                f4 a, b;
-                fetchRay<PRIMARY>(sc, src, idx, a, b);
-                d = mk3(a.w, b.x, b.y);
-                R = makeOctRay(mk3(a.x, a.y, a.z), d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));
-                best_t = SHADOW ? b.w : TRT_INF; best_tri = -1; best_flags = 0u;  // shadow rays carry a bound: t_max (any) or a search hint
-                sp = 0;
-                ng.x = 0u; ng.y = 0x80000000u;  // the root
-                tg.y = 0u;
-            }
-            const uint32_t taken = (uint32_t)__popcll(m_free);
-            c_next = (c_end - c_next) < taken ? c_end : c_next + taken;
+            if (ballotb((tg.y | (ng.y & 0xFF000000u)) != 0u) == 0ull) break;  // nothing left in the slice
         }
+
         const bool is_leaf = tg.y != 0u;
         const bool is_inner = !is_leaf && (ng.y & 0xFF000000u) != 0u;
         const unsigned long long m_in = ballotb(is_inner), m_lf = ballotb(is_leaf);
-        if ((m_in | m_lf) == 0ull) {
-            if (exhausted) break;  // no lane holds a ray and the queue is empty
-            continue;
+        if (COUNT) {
+            const unsigned long long m_dn = ballotb(!is_leaf && !is_inner && idx != NO_RAY);
+            if (lane == 0) { pr.c_in += (uint32_t)__popcll(m_in); pr.c_lf += (uint32_t)__popcll(m_lf); pr.c_done += (uint32_t)__popcll(m_dn); pr.c_it++; }
         }
-        if (COUNT && lane == 0) { pr.c_in += (uint32_t)__popcll(m_in); pr.c_lf += (uint32_t)__popcll(m_lf); pr.c_it++; }
         bool adv = false;  // the lane has used up its groups: next group off the stack, or the ray is finished
         if (sc.sched_in_w * (uint32_t)__popcll(m_in) >= sc.sched_lf_w * (uint32_t)__popcll(m_lf)) {
             if (is_inner) {
@@ -657,12 +613,16 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
             }
         } else {
             if (is_leaf) {
-                const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
-                tg.y &= tg.y - 1u;
-                const TriIsect T = sc.tri_trav[tg.x + b];
-                if (COUNT) { pr.n_tri++; if (lane == (uint32_t)__ffsll((long long)m_lf) - 1u) pr.wave_tri++; }
-                float t, un, vn, det;
-                if (triTest(T, R.o, d, t, un, vn, det)) octFold(t, f2u(T.c.w), f2u(T.c.z), best_t, best_tri, best_flags);
+                // up to TRT_OCT_LEAF_LOOP triangles of the lane's group per step
+#pragma unroll 1
+                for (int rep = 0; rep < TRT_OCT_LEAF_LOOP && tg.y != 0u; ++rep) {
+                    const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
+                    tg.y &= tg.y - 1u;
+                    const TriIsect T = sc.tri_trav[tg.x + b];
+                    if (COUNT) { pr.n_tri++; if (rep == 0 && lane == (uint32_t)__ffsll((long long)m_lf) - 1u) pr.wave_tri++; }
+                    float t, un, vn, det;
+                    if (triTest(T, R.o, d, t, un, vn, det)) octFold(t, f2u(T.c.w), f2u(T.c.z), best_t, best_tri, best_flags);
+                }
                 if (tg.y == 0u) {
                     if (any && best_tri >= 0) { ng.y = 0u; sp = 0; }  // occlusion test: the first leaf that yields a hit ends the ray
                     adv = (ng.y & 0xFF000000u) == 0u;
@@ -672,10 +632,9 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
         if (adv) {
             if (sp != 0 && !(any && best_tri >= 0)) ng = stk.pop(--sp);
             else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; ng.x = 0u; ng.y = 0x80000000u; }  // nothing in front of the hint: search again without it
-            else ng.y = 0u;  // finished: parked at the top of the next iteration
+            else ng.y = 0u;  // finished
         }
     }
-    if (n_park != 0u) flush(0u, n_park);  // fewer than 64 are left
     if (COUNT) {
         const unsigned long long si = waveSum(pr.n_inner), st = waveSum(pr.n_tri), wi = waveSum(pr.wave_inner), wt = waveSum(pr.wave_tri);
         if (lane == 0) {
@@ -685,15 +644,8 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
             atomicAdd(&stats->wave_leaf_steps, wt);
             atomicAdd(&stats->census_inner, (unsigned long long)pr.c_in);
             atomicAdd(&stats->census_leaf, (unsigned long long)pr.c_lf);
+            atomicAdd(&stats->census_done, (unsigned long long)pr.c_done);
             atomicAdd(&stats->census_iters, (unsigned long long)pr.c_it);
-        }
-    }
-    // the last block of the launch leaves the counters at zero for the next one
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(redo.qctl + TRT_OCT_QUEUES, 1u) + 1u == gridDim.x) {
-            for (int k = 0; k <= TRT_OCT_QUEUES; ++k) redo.qctl[k] = 0u;
         }
     }
 }
@@ -714,7 +666,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 * DEPTH * TRT_TRACE_BLOCK + (TRT_TRACE_BLOCK / 64) * TRT_PARK * 4 : DEPTH * TRT_TRACE_BLOCK)];  // stack (8-byte entries + the parked results on the oct tree), or (uniform walk) the candidate queue
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];  // stack (8-byte entries on the oct tree), or (uniform walk) the candidate queue
     traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false, redo);
 }
 
@@ -726,7 +678,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 * DEPTH * TRT_TRACE_BLOCK + (TRT_TRACE_BLOCK / 64) * TRT_PARK * 4 : DEPTH * TRT_TRACE_BLOCK)];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;
