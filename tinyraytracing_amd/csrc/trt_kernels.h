@@ -530,6 +530,9 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
 #ifndef TRT_OCT_LEAF_LOOP
 #define TRT_OCT_LEAF_LOOP 1
 #endif
+#ifndef TRT_OCT_TOP
+#define TRT_OCT_TOP 9  // nodes of the tree kept in LDS by the oct kernels: the root and its (at most eight) inner children
+#endif
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
 __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
@@ -539,6 +542,11 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     stk.lds = smem + threadIdx.x;
     stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
     stk.spill_stride = spill_stride;
+    // the top of the tree — the root and its inner children: nodes[0 .. ntop), breadth-first layout — in LDS behind the stack
+    f4* const top = reinterpret_cast<f4*>(smem + 2 * DEPTH * TRT_TRACE_BLOCK);
+    const uint32_t ntop = sc.n_onodes < (uint32_t)TRT_OCT_TOP ? sc.n_onodes : (uint32_t)TRT_OCT_TOP;
+    if (threadIdx.x < ntop * 5u) top[threadIdx.x] = reinterpret_cast<const f4*>(sc.onodes)[threadIdx.x];
+    __syncthreads();
     const bool any = SHADOW && any_flag;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lower = (1ull << lane) - 1ull;
@@ -608,7 +616,7 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
                 const uint32_t ni = octNextChild(ng, R);
                 if (ng.y & 0xFF000000u) stk.push(sp++, ng);
-                octVisit(sc.onodes, ni, R, trt_cull_bound(best_t, sc.leaf_alpha), ng, tg);
+                octVisit(sc.onodes, ni, R, trt_cull_bound(best_t, sc.leaf_alpha), ng, tg, top, ntop);
                 adv = (tg.y | (ng.y & 0xFF000000u)) == 0u;
             }
         } else {
@@ -666,7 +674,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];  // stack (8-byte entries on the oct tree), or (uniform walk) the candidate queue
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 * DEPTH * TRT_TRACE_BLOCK + TRT_OCT_TOP * 20 : DEPTH * TRT_TRACE_BLOCK)];  // stack (8-byte entries on the oct tree, + the top of that tree), or (uniform walk) the candidate queue
     traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false, redo);
 }
 
@@ -678,7 +686,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 * DEPTH * TRT_TRACE_BLOCK + TRT_OCT_TOP * 20 : DEPTH * TRT_TRACE_BLOCK)];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;

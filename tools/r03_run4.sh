@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round 3, GPU call 4: top-of-tree in LDS (TRT_OCT_TOP 0 / 9 / 73), leaf loop (1 / 2 / 3 triangles per leaf step); counters of the default build.
+root=${GRAFT_REPO_ROOT:-/root/repo}
+cd $root
+mkdir -p gpurun_out/r03/ab4
+export PYTHONUNBUFFERED=1
+echo "== parity subset"
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "node_kind or compressed or degenerate or grazing or redo or unpadded or golden or incoherent or soup or tiny or image_matches or fixed_nee" 2>&1 | tail -4
+test ${PIPESTATUS[0]} -eq 0 || exit 1
+run() { # tag envs args...
+  tag=$1; envs=$2; shift 2
+  env $envs timeout -k 10 400 python bench.py "$@" --no-cpu-baseline --no-extra --no-overlap-extra > gpurun_out/r03/ab4/$tag.json 2> gpurun_out/r03/ab4/$tag.err || echo "$tag failed"
+  python - gpurun_out/r03/ab4/$tag.json "$tag" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    k = {a: b["ms_per_step"] for a, b in d["kernels_rank0"].items() if b["ms_per_step"]}
+    u = d["simd_utilisation_traversal"]
+    print(f'{sys.argv[2]:30s} {d["value"]:9.1f} Mrays/s {d["ms_per_step"]:9.2f} ms  closest {k.get("trace_closest", 0):8.2f} shade {k.get("shade", 0):7.2f} shadow {k.get("trace_shadow", 0):8.2f} tail {k.get("tail", 0):6.2f} | lanes {u["inner_steps"]}/{u["leaf_steps"]} visits {u["visits_per_ray"]} tests {u["tri_tests_per_ray"]}', flush=True)
+except Exception as e:
+    print(sys.argv[2], "no result", e, flush=True)
+PY
+}
+V=$root/tinyraytracing_amd/lib/variants
+scene_args() {
+  case $1 in
+    veach) echo "--scene veach-mis --steps 2";;
+    stair) echo "--scene staircase --spp 64 --steps 2";;
+    soup) echo "--scene soup --spp 16 --steps 2";;
+    blob2m) echo "--scene blob --tris 2000000 --spp 64 --steps 2";;
+    blob10m) echo "--scene blob --tris 10000000 --width 3840 --height 2160 --spp 16 --steps 2";;
+  esac
+}
+for sc in veach stair soup blob2m blob10m; do
+  a=$(scene_args $sc)
+  run ${sc}_top9 "TRT_NODE_KIND=1" $a
+  for v in top0 top73 ll2 ll3; do run ${sc}_$v "TRT_NODE_KIND=1 TRT_HIP_LIB=$V/libtrt_hip_$v.so" $a; done
+done
+echo "== counters (default build)"
+tools/roofs.sh r03_stair "--scene staircase --spp 64" > gpurun_out/r03/roofs_stair.log 2>&1; tail -40 gpurun_out/roofs_r03_stair/summary.txt
+tools/roofs.sh r03_veach "--scene veach-mis --spp 64" > gpurun_out/r03/roofs_veach.log 2>&1; tail -30 gpurun_out/roofs_r03_veach/summary.txt
