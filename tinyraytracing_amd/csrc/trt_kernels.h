@@ -545,7 +545,7 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     // the top of the tree — the root and its inner children: nodes[0 .. ntop), breadth-first layout — in LDS behind the stack
     f4* const top = reinterpret_cast<f4*>(smem + 2 * DEPTH * TRT_TRACE_BLOCK);
     const uint32_t ntop = sc.n_onodes < (uint32_t)TRT_OCT_TOP ? sc.n_onodes : (uint32_t)TRT_OCT_TOP;
-    if (threadIdx.x < ntop * 5u) top[threadIdx.x] = reinterpret_cast<const f4*>(sc.onodes)[threadIdx.x];
+    for (uint32_t w = threadIdx.x; w < ntop * 5u; w += TRT_TRACE_BLOCK) top[w] = reinterpret_cast<const f4*>(sc.onodes)[w];
     __syncthreads();
     const bool any = SHADOW && any_flag;
     const uint32_t lane = threadIdx.x & 63u;

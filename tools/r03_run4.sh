@@ -31,10 +31,10 @@ scene_args() {
     blob10m) echo "--scene blob --tris 10000000 --width 3840 --height 2160 --spp 16 --steps 2";;
   esac
 }
-for sc in veach stair soup blob2m blob10m; do
+for sc in stair soup blob2m blob10m veach; do
   a=$(scene_args $sc)
   run ${sc}_top9 "TRT_NODE_KIND=1" $a
-  for v in top0 top73 ll2 ll3; do run ${sc}_$v "TRT_NODE_KIND=1 TRT_HIP_LIB=$V/libtrt_hip_$v.so" $a; done
+  for v in top0 ll2 ll3; do run ${sc}_$v "TRT_NODE_KIND=1 TRT_HIP_LIB=$V/libtrt_hip_$v.so" $a; done
 done
 echo "== counters (default build)"
 tools/roofs.sh r03_stair "--scene staircase --spp 64" > gpurun_out/r03/roofs_stair.log 2>&1; tail -40 gpurun_out/roofs_r03_stair/summary.txt
