@@ -54,7 +54,7 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h 
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options
-VARIANTS := top0=-DTRT_OCT_TOP=0 ll2=-DTRT_OCT_LEAF_LOOP=2 ll3=-DTRT_OCT_LEAF_LOOP=3
+VARIANTS := w8=-DTRT_TRACE_MINWAVES=8
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
 	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \

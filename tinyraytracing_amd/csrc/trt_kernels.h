@@ -525,13 +525,15 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
 // stored yet.  Results are checked when they are stored (checkedStore<.., OCT>): the ray must pass the exact box of its hit's leaf.
 // (Round 3 also tried rays fetched from the launch's queue through atomic counters, in chunks, with finished rays parked in LDS and
 // stored 64 at a time: lanes per step 0.55 / 0.45 -> 0.64 / 0.57, and 20-30 % SLOWER on every scene — 28 KiB of LDS and 84 VGPRs
-// leave five waves per SIMD instead of seven, and these kernels live on the texture addresser's lane-load rate, not on VALU
-// issue: profiles/r03_ab_oct.txt.  Static slices stay.)
+// leave five waves per SIMD instead of seven, and the parked results cost a second fetch of their rays: more instructions per ray
+// than the busier lanes save: profiles/r03_ab_oct.txt.  Static slices stay.)
+// TRT_OCT_LEAF_LOOP: triangles a lane tests per leaf step.  Leaves hold two: with 2 the second one follows at once, without another
+// round of votes, and the lane is back at a node with its neighbours (lanes per leaf step 0.45 -> 0.88; staircase, veach-mis +4 %,
+// the meshes +2-3 %; 3: no better).
+// (Also measured: the root and its children read from an LDS copy — a fifth of all node fetches on veach-mis —: +-0.3 %.  These kernels
+// are bound by VALU issue, profiles/r03_roofs_stair.txt, not by the texture addresser.  Removed.)
 #ifndef TRT_OCT_LEAF_LOOP
-#define TRT_OCT_LEAF_LOOP 1
-#endif
-#ifndef TRT_OCT_TOP
-#define TRT_OCT_TOP 9  // nodes of the tree kept in LDS by the oct kernels: the root and its (at most eight) inner children
+#define TRT_OCT_LEAF_LOOP 2
 #endif
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
 __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
@@ -542,11 +544,6 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     stk.lds = smem + threadIdx.x;
     stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
     stk.spill_stride = spill_stride;
-    // the top of the tree — the root and its inner children: nodes[0 .. ntop), breadth-first layout — in LDS behind the stack
-    f4* const top = reinterpret_cast<f4*>(smem + 2 * DEPTH * TRT_TRACE_BLOCK);
-    const uint32_t ntop = sc.n_onodes < (uint32_t)TRT_OCT_TOP ? sc.n_onodes : (uint32_t)TRT_OCT_TOP;
-    for (uint32_t w = threadIdx.x; w < ntop * 5u; w += TRT_TRACE_BLOCK) top[w] = reinterpret_cast<const f4*>(sc.onodes)[w];
-    __syncthreads();
     const bool any = SHADOW && any_flag;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lower = (1ull << lane) - 1ull;
@@ -616,7 +613,7 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
                 const uint32_t ni = octNextChild(ng, R);
                 if (ng.y & 0xFF000000u) stk.push(sp++, ng);
-                octVisit(sc.onodes, ni, R, trt_cull_bound(best_t, sc.leaf_alpha), ng, tg, top, ntop);
+                octVisit(sc.onodes, ni, R, trt_cull_bound(best_t, sc.leaf_alpha), ng, tg);
                 adv = (tg.y | (ng.y & 0xFF000000u)) == 0u;
             }
         } else {
@@ -674,7 +671,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 * DEPTH * TRT_TRACE_BLOCK + TRT_OCT_TOP * 20 : DEPTH * TRT_TRACE_BLOCK)];  // stack (8-byte entries on the oct tree, + the top of that tree), or (uniform walk) the candidate queue
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];  // stack (8-byte entries on the oct tree), or (uniform walk) the candidate queue
     traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false, redo);
 }
 
@@ -686,7 +683,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 * DEPTH * TRT_TRACE_BLOCK + TRT_OCT_TOP * 20 : DEPTH * TRT_TRACE_BLOCK)];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;

@@ -90,23 +90,10 @@ TRT_HD inline float octByte(uint32_t w, int k) { return (float)((w >> (8 * k)) &
 
 // One visit of node `ni`: the hit mask of its eight children (see the header): inner children in bits 24..31 at position
 // 24 + (slot ^ octinv), triangles of leaf children in bits 0..23.  `cull` = trt_cull_bound(best hit so far).
-// `top` / `ntop` (kernels): a copy of nodes[0 .. ntop) in LDS — the root and its inner children (the tree is laid out breadth first) —
-// which every ray visits: read from there they cost the CU's texture addresser nothing (that unit's lane-load
-// rate is what the traversal kernels live on).
-TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, const OctRay& R, float cull, OctGroup& ng, OctGroup& tg, const f4* top = nullptr,
-                            uint32_t ntop = 0u)
+TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, const OctRay& R, float cull, OctGroup& ng, OctGroup& tg)
 {
-    f4 q0, q1, q2, q3, q4;
-    if (ni < ntop) {
-        const f4* q = top + ni * 5u;
-        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4];
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x), "+v"(q4.x));  // keeps these ds_reads (merged with the global loads they would become FLAT ones)
-#endif
-    } else {
-        const f4* q = nodes[ni].q;
-        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4];
-    }
+    const f4* q = nodes[ni].q;
+    const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
     const uint32_t ew = f2u(q0.w);
     // ray in the node's frame: t(bound byte b) = b * idir + org, widened by m (header, (1))
     const float idx = u2f((ew & 0xFFu) << 23) * R.inv.x, idy = u2f(((ew >> 8) & 0xFFu) << 23) * R.inv.y, idz = u2f(((ew >> 16) & 0xFFu) << 23) * R.inv.z;
