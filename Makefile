@@ -49,7 +49,7 @@ $(OUT)/libtrt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
-$(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(PKG)/host/render.h $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so
+$(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -fopenmp -Wl,-rpath,'$$ORIGIN'
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
