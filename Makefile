@@ -54,7 +54,7 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) $(OUT)/li
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options
-VARIANTS := eg7=-DTRT_OCT_EAGER=1+-DTRT_OCT_LDS_LEVELS=8+-DTRT_TRACE_MINWAVES=7 eg=-DTRT_OCT_EAGER=1+-DTRT_OCT_LDS_LEVELS=8 w8=-DTRT_TRACE_MINWAVES=8 l8=-DTRT_OCT_LDS_LEVELS=8
+VARIANTS := w8=-DTRT_TRACE_MINWAVES=8
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
 	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \

@@ -302,11 +302,8 @@ struct Timer {
     } while (0)
 // The oct tree needs one 8-byte entry per level below the root: OCT_LDS_LEVELS of them in LDS (20 KiB per block: eight blocks per CU),
 // deeper ones — staircase has 10 levels, the 10 M-triangle mesh 11 — in the global spill area.  One instantiation serves every tree.
-#ifndef TRT_OCT_LDS_LEVELS
-#define TRT_OCT_LDS_LEVELS 10
-#endif
-constexpr uint32_t OCT_LDS_LEVELS = TRT_OCT_LDS_LEVELS;
-#define TRT_BY_OCT_DEPTH(LAUNCH) LAUNCH(TRT_OCT_LDS_LEVELS, true, 3, 1)
+constexpr uint32_t OCT_LDS_LEVELS = 10;
+#define TRT_BY_OCT_DEPTH(LAUNCH) LAUNCH(10, true, 3, 1)
 // Behind every traversal launch of a per-lane driver: k_trace_fix (a few blocks) traces the rays of the launch's redo list again in the
 // exact form (trt_kernels.h, RedoList).  The wave-uniform walk applies the rule on the spot and has no list.
 template <bool COUNT, bool PRIMARY>

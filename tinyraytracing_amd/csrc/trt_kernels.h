@@ -526,7 +526,11 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
 // (Round 3 also tried rays fetched from the launch's queue through atomic counters, in chunks, with finished rays parked in LDS and
 // stored 64 at a time: lanes per step 0.55 / 0.45 -> 0.64 / 0.57, and 20-30 % SLOWER on every scene — 28 KiB of LDS and 84 VGPRs
 // leave five waves per SIMD instead of seven, and the parked results cost a second fetch of their rays: more instructions per ray
-// than the busier lanes save: profiles/r03_ab_oct.txt.  Static slices stay.)
+// than the busier lanes save.  And, on static slices, NO refill batches at all — a free lane takes the next ray at the beginning of the
+// next node step, finished rays parked as above —: lanes per step 0.57 / 0.88 -> 0.69 / 1.12 (two triangles per leaf step) and 14-40 %
+// slower: the ray fetch and its three reciprocals then run in almost every node step for a handful of lanes.  These kernels are bound
+// by VALU ISSUE (profiles/r03_roofs_stair_oct.txt): what counts is wave-level instructions per ray, and a refill batch of 48 amortises
+// 200 of them over 48 rays.  profiles/r03_ab_oct.txt has all of it.  Static slices and batches stay.)
 // TRT_OCT_LEAF_LOOP: triangles a lane tests per leaf step.  Leaves hold two: with 2 the second one follows at once, without another
 // round of votes, and the lane is back at a node with its neighbours (lanes per leaf step 0.45 -> 0.88; staircase, veach-mis +4 %,
 // the meshes +2-3 %; 3: no better).
@@ -655,174 +659,13 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     }
 }
 
-// EXPERIMENT (build option TRT_OCT_EAGER): the same driver with no refill batches.  A free lane takes the next ray of the wave's slice
-// at the beginning of the next NODE step (its first step is the visit of the root anyway), and a finished ray is parked — (queue
-// index, t, triangle, flags) in a per-wave LDS buffer — so that its lane is free at once; parked results are checked and stored
-// TRT_PARK_FLUSH or more at a time, on the ray re-read from the queue.
-#ifndef TRT_OCT_EAGER
-#define TRT_OCT_EAGER 0
-#endif
-constexpr int TRT_PARK_CAP = 96, TRT_PARK_FLUSH = 32;
-template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
-__device__ __forceinline__ void traceQueueEagerOct(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
-                                           const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
-{
-    OctLdsStack<DEPTH, SPILL> stk;
-    stk.lds = smem + threadIdx.x;
-    stk.spill = spill + (size_t)blockIdx.x * TRT_TRACE_BLOCK + threadIdx.x;
-    stk.spill_stride = spill_stride;
-    f4* const park = reinterpret_cast<f4*>(smem + 2 * DEPTH * TRT_TRACE_BLOCK) + (threadIdx.x >> 6) * TRT_PARK_CAP;
-    uint32_t n_park = 0;  // wave-uniform
-    const bool any = SHADOW && any_flag;
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lower = (1ull << lane) - 1ull;
-    const uint32_t n_waves = gridDim.x * (TRT_TRACE_BLOCK / 64);
-    const uint32_t wave = xcdSwizzle(blockIdx.x, gridDim.x) * (TRT_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
-    const uint32_t per = (n + n_waves - 1) / n_waves;
-    const unsigned long long w0 = (unsigned long long)wave * per;
-    uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w0 < n ? w0 : n));
-    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)((w0 + per) < n ? (w0 + per) : n));
-
-    constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
-    uint32_t idx = NO_RAY;
-    int sp = 0;
-    OctGroup ng, tg;
-    ng.x = 0u; ng.y = 0u; tg.x = 0u; tg.y = 0u;
-    f3 d = mk3(0, 0, 0);
-    OctRay R;
-    R.o = mk3(0, 0, 0); R.inv = mk3(0, 0, 0); R.octinv4 = 0u;
-    float best_t = TRT_INF;
-    int32_t best_tri = -1;
-    uint32_t best_flags = 0;
-    TraceProbe pr;
-
-    // parked results [first, first + count), one per lane: the check of the result against the exact box of its leaf, then the store —
-    // in sequence (every lane is busy here; few values live at a time, so that the traversal loop keeps its registers)
-    auto flush = [&](uint32_t first, uint32_t count) {
-        if (lane < count) {
-            const f4 e = park[first + lane];
-            const uint32_t i = f2u(e.x);
-            const float pt = e.y;
-            const int32_t ptri = (int32_t)f2u(e.z);
-            const uint32_t pfl = f2u(e.w);
-            f4 a, b;
-            fetchRay<PRIMARY>(sc, src, i, a, b);
-            const f3 fo = mk3(a.x, a.y, a.z), fd = mk3(a.w, b.x, b.y);
-            bool ok = true;
-            if (ptri >= 0) {
-                const f3 inv = mk3(1.0f / fd.x, 1.0f / fd.y, 1.0f / fd.z);
-                const f4 ba = sc.leaf_box[2 * (size_t)ptri], bb = sc.leaf_box[2 * (size_t)ptri + 1];
-                float en;
-                const bool pass = boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, fo, inv, en);
-                ok = pass && !(pt < trt_leaf_floor(en, sc.leaf_alpha));
-            }
-            if (!ok) redo.idx[atomicAdd(redo.count, 1u)] = i;
-            else storeResult<SHADOW>(sc, fo, fd, pt, ptri, pfl, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
-        }
-    };
-
-    for (;;) {
-        const bool is_leaf = tg.y != 0u;
-        const bool is_inner = !is_leaf && (ng.y & 0xFF000000u) != 0u;
-        const bool is_free = idx == NO_RAY;
-        const bool can_fill = next < end;
-        const unsigned long long m_in = ballotb(is_inner), m_lf = ballotb(is_leaf), m_free = ballotb(is_free);
-        const uint32_t n_new = can_fill ? (uint32_t)__popcll(m_free) : 0u;
-        if ((m_in | m_lf) == 0ull && n_new == 0u) break;  // no ray in flight, none left in the slice
-        if (COUNT && lane == 0) { pr.c_in += (uint32_t)__popcll(m_in); pr.c_lf += (uint32_t)__popcll(m_lf); pr.c_it++; }
-        bool fin = false;  // the lane's ray ends in this iteration
-        if (sc.sched_in_w * ((uint32_t)__popcll(m_in) + n_new) >= sc.sched_lf_w * (uint32_t)__popcll(m_lf)) {
-            // ---- node step; free lanes first take a ray (their step is the visit of the root)
-            bool visit = is_inner;
-            if (n_new != 0u) {
-                const uint32_t i = next + (uint32_t)__popcll(m_free & lower);
-                if (is_free && i < end) {
-                    idx = i;
-                    f4 a, b;
-                    fetchRay<PRIMARY>(sc, src, idx, a, b);
-                    d = mk3(a.w, b.x, b.y);
-                    R = makeOctRay(mk3(a.x, a.y, a.z), d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));
-                    best_t = SHADOW ? b.w : TRT_INF; best_tri = -1; best_flags = 0u;
-                    sp = 0;
-                    ng.x = 0u; ng.y = 0x80000000u;  // the root
-                    tg.y = 0u;
-                    visit = true;
-                }
-                next = (end - next) < n_new ? end : next + n_new;
-            }
-            if (visit) {
-                if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)ballotb(visit)) - 1u) pr.wave_inner++; }
-                const uint32_t ni = octNextChild(ng, R);
-                if (ng.y & 0xFF000000u) stk.push(sp++, ng);
-                octVisit(sc.onodes, ni, R, trt_cull_bound(best_t, sc.leaf_alpha), ng, tg);
-                if ((tg.y | (ng.y & 0xFF000000u)) == 0u) {
-                    if (sp != 0) ng = stk.pop(--sp);
-                    else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; ng.x = 0u; ng.y = 0x80000000u; }
-                    else fin = true;
-                }
-            }
-        } else if (is_leaf) {
-#pragma unroll 1
-            for (int rep = 0; rep < TRT_OCT_LEAF_LOOP && tg.y != 0u; ++rep) {
-                const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
-                tg.y &= tg.y - 1u;
-                const TriIsect T = sc.tri_trav[tg.x + b];
-                if (COUNT) { pr.n_tri++; if (rep == 0 && lane == (uint32_t)__ffsll((long long)m_lf) - 1u) pr.wave_tri++; }
-                float t, un, vn, det;
-                if (triTest(T, R.o, d, t, un, vn, det)) octFold(t, f2u(T.c.w), f2u(T.c.z), best_t, best_tri, best_flags);
-            }
-            if (tg.y == 0u) {
-                if (any && best_tri >= 0) { ng.y = 0u; sp = 0; }
-                if ((ng.y & 0xFF000000u) == 0u) {
-                    if (sp != 0) ng = stk.pop(--sp);
-                    else if (SHADOW && !any && best_tri < 0 && best_t < TRT_INF) { best_t = TRT_INF; ng.x = 0u; ng.y = 0x80000000u; }
-                    else fin = true;
-                }
-            }
-        }
-        // ---- finished rays are parked, their lanes are free at once
-        const unsigned long long m_fin = ballotb(fin);
-        if (m_fin != 0ull) {
-            if (fin) {
-                park[n_park + (uint32_t)__popcll(m_fin & lower)] = mk4(u2f(idx), best_t, u2f((uint32_t)best_tri), u2f(best_flags));
-                idx = NO_RAY;
-                ng.y = 0u; tg.y = 0u;
-            }
-            n_park += (uint32_t)__popcll(m_fin);
-            while (n_park >= (uint32_t)TRT_PARK_FLUSH) {
-                const uint32_t c = n_park < 64u ? n_park : 64u;
-                flush(n_park - c, c);
-                n_park -= c;
-            }
-        }
-    }
-    if (n_park != 0u) flush(0u, n_park);
-    if (COUNT) {
-        const unsigned long long si = waveSum(pr.n_inner), st = waveSum(pr.n_tri), wi = waveSum(pr.wave_inner), wt = waveSum(pr.wave_tri);
-        if (lane == 0) {
-            atomicAdd(&stats->inner_visits[SHADOW ? 1 : 0], si);
-            atomicAdd(&stats->tri_tests[SHADOW ? 1 : 0], st);
-            atomicAdd(&stats->wave_inner_steps, wi);
-            atomicAdd(&stats->wave_leaf_steps, wt);
-            atomicAdd(&stats->census_inner, (unsigned long long)pr.c_in);
-            atomicAdd(&stats->census_leaf, (unsigned long long)pr.c_lf);
-            atomicAdd(&stats->census_iters, (unsigned long long)pr.c_it);
-        }
-    }
-}
-
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueue(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
                                            uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
 {
     if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats, any_flag, reinterpret_cast<f4*>(smem));
-#if TRT_OCT_EAGER
-    else if constexpr (NK == 1) traceQueueEagerOct<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
-#else
     else if constexpr (NK == 1) traceQueuePersistentOct<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
-#endif
     else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
 }
 
@@ -832,7 +675,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4* __restrict__ hit, uint32_t n,
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 * DEPTH * TRT_TRACE_BLOCK + (TRT_OCT_EAGER ? (TRT_TRACE_BLOCK / 64) * TRT_PARK_CAP * 4 : 0) : DEPTH * TRT_TRACE_BLOCK)];  // stack (8-byte entries on the oct tree), or (uniform walk) the candidate queue
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];  // stack (8-byte entries on the oct tree), or (uniform walk) the candidate queue
     traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false, redo);
 }
 
@@ -844,7 +687,7 @@ template <bool COUNT, int DEPTH, bool SPILL, int IMPL, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
                                                 uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any, RedoList redo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 * DEPTH * TRT_TRACE_BLOCK + (TRT_OCT_EAGER ? (TRT_TRACE_BLOCK / 64) * TRT_PARK_CAP * 4 : 0) : DEPTH * TRT_TRACE_BLOCK)];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;
