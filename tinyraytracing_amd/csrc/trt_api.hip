@@ -927,7 +927,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     st.lane_census[0] = ds.census_inner; st.lane_census[1] = ds.census_leaf; st.lane_census[2] = ds.census_done; st.lane_census[3] = ds.census_iters;
     st.passes = n_chunks;
     st.rows_rendered = rows.size();
-    st.inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(OctNode) : (uint32_t)sizeof(WideNode));
+    st.inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? 80u : (uint32_t)sizeof(WideNode));
     if (stats_out) *stats_out = st;
     return TRT_OK;
 }
@@ -1031,7 +1031,7 @@ int trt_trace_closest(trt_handle* h, uint64_t n, const float* org, const float* 
         stats_out->wave_steps[1] = ds.wave_leaf_steps;
         stats_out->kernel_ms[TRT_K_TRACE_CLOSEST] = ms;
         stats_out->launches[TRT_K_TRACE_CLOSEST] = 1;
-        stats_out->inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? (uint32_t)sizeof(OctNode) : (uint32_t)sizeof(WideNode));
+        stats_out->inner_node_bytes = h->trace_impl == 0 ? (uint32_t)sizeof(trt_bvh_node) : (h->node_kind == 1 ? 80u : (uint32_t)sizeof(WideNode));
         stats_out->redo_rays = ds.redo_rays;
         stats_out->lane_census[0] = ds.census_inner; stats_out->lane_census[1] = ds.census_leaf; stats_out->lane_census[2] = ds.census_done; stats_out->lane_census[3] = ds.census_iters;
     }

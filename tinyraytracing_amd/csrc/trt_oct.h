@@ -53,10 +53,15 @@
 
 namespace trtd {
 
-struct OctNode {
+// TRT_OCT_NODE_ALIGN: 16 = nodes packed at a stride of 80 B (a node then straddles two 128-B lines 3 times in 8); 128 = one node per line
+// (1.6x the node memory, one line per visit).
+#ifndef TRT_OCT_NODE_ALIGN
+#define TRT_OCT_NODE_ALIGN 16
+#endif
+struct alignas(TRT_OCT_NODE_ALIGN) OctNode {
     f4 q[5];
 };
-static_assert(sizeof(OctNode) == 80, "OctNode is five 16-byte words");
+static_assert(sizeof(OctNode) == (TRT_OCT_NODE_ALIGN == 128 ? 128 : 80), "OctNode is five 16-byte words (+ padding to a line)");
 
 #define TRT_OCT_MAX_LEAF_TRIS 3u
 

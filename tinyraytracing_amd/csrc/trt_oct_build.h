@@ -109,14 +109,15 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
         int n = 0;
         {
             struct Item { Entry en; int k; };
-            std::vector<Item> stack;
+            Item stack[2 * W];  // at most W entries wait at a time (every item stands for >= 1 of the <= W children)
+            int top = 0;
             Entry c[2];
             children(nodes2[j.bvh2], c);
             const int i = split_root[j.bvh2];
-            stack.push_back({c[1], W - i});
-            stack.push_back({c[0], i});
-            while (!stack.empty()) {
-                const Item it = stack.back(); stack.pop_back();
+            stack[top++] = {c[1], W - i};
+            stack[top++] = {c[0], i};
+            while (top > 0) {
+                const Item it = stack[--top];
                 const uint32_t ref = it.en.ref;
                 const int s = (ref & TRT_LEAF_BIT) ? 0 : split_k[(size_t)ref * (W - 1) + (it.k - 1)];
                 if (s == 0) {
@@ -125,8 +126,8 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
                 }
                 Entry g[2];
                 children(nodes2[ref], g);
-                stack.push_back({g[1], it.k - s});
-                stack.push_back({g[0], s});
+                stack[top++] = {g[1], it.k - s};
+                stack[top++] = {g[0], s};
             }
         }
         // frame
