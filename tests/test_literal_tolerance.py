@@ -170,6 +170,25 @@ def test_closest_hits_of_the_two_formulations_on_the_scenes():
         assert np.percentile(duv, 99) < 2e-4 and duv.max() < 2e-2, (name, np.percentile(duv, 99), duv.max())
 
 
+@pytest.mark.parametrize("name", ["veach-mis", "staircase"])
+def test_the_two_formulations_on_grazing_rays(name):
+    """the leaf-box rule lives in the fast oracle AND in the kernels (it was added to both in one commit), so what keeps
+    it honest is the literal oracle, which has no such rule.  On rays at 1e-5 .. 1e-2 rad from the plane of a random triangle — the rays
+    the rule exists for, where BOTH formulations' distances are least accurate — the two disagree on 2.1-2.4 % of the rays (another triangle,
+    or t off by more than 1e-4), and they do so SYMMETRICALLY: the reference's arithmetic reports the nearer hit as often as the fast one
+    (4 491 against 4 580 of 60 000 on veach-mis, 965 / 996 on staircase; hit where the other misses: 78 / 80 and 201 / 125).  A rule that
+    threw honest hits away would show up as the fast formulation reporting the FARTHER hit more often."""
+    s = get_scene(name, 64, 36)
+    org, dirs = raygen.grazing_rays(s.flat, 60000, seed=21)
+    tf, trif, _ = O.trace(s.flat, org, dirs)
+    tl, tril, _ = O.trace_literal(s.flat, org, dirs)
+    assert (trif == tril).mean() >= 0.97, (name, (trif == tril).mean())
+    lit_nearer = int(((tril >= 0) & ((trif < 0) | (tl < tf * (1 - 1e-4)))).sum())
+    fast_nearer = int(((trif >= 0) & ((tril < 0) | (tf < tl * (1 - 1e-4)))).sum())
+    assert abs(lit_nearer - fast_nearer) <= 0.12 * (lit_nearer + fast_nearer), (name, lit_nearer, fast_nearer)
+    assert lit_nearer <= 0.1 * len(tf)
+
+
 @pytest.mark.gpu
 def test_config2_hip_image_within_the_stated_tolerance_of_the_reference_arithmetic(renderer_factory):
     """BASELINE config 2 at full size — back, 1024 x 1024, 256 spp, seeded RNG — rendered by the HIP path through the C-ABI

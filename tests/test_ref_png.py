@@ -9,9 +9,11 @@ the committed code produces: geometry, the pixel grid (Q1/Q2), the estimator, an
 Which snapshot belongs to the committed code was established by ranking all of them against the parity-mode render
 (tools/rank_ref_png.py):
 
-  veach-mis/image10.png   matches parity mode to 1.3 % median block error, correlation 0.9992 — and NOT TRT_FLAG_FIXED_NEE
-                          (23 %): the three-light bias of Q3 (every CDF draw spans light 1's area), Q4 and Q5 are in the
-                          reference's own output, and the restatement reproduces them.
+  (Two sets of numbers appear below and in DESIGN.md §2; they differ because the renders do: the CPU tests of this file use the ORACLE at
+  2-8 spp — 1.3 % / 7 % / 9 % —, the -m gpu tests and DESIGN.md's table the HIP path at the snapshot's own sample count — 1.05 % / 5.5 % / 5.7 %.)
+  veach-mis/image10.png   matches parity mode to 1.3 % median block error, correlation 0.9992 (oracle, 4 spp; HIP at 10 spp: 1.05 %, on the
+                          two-seed floor of 1.07 %) — and NOT TRT_FLAG_FIXED_NEE (23 %): the three-light bias of Q3 (every CDF draw spans
+                          light 1's area), Q4 and Q5 are in the reference's own output, and the restatement reproduces them.
   staircase/image10.png   parity 7 % at 2 spp, 5.5 % at the snapshot's own 10 spp; fixed-NEE 20 %: same conclusion on six lights and
                           three textures (texture orientation and the BGR order of pathTracing.cpp:24-25 included).  NOT all of it is
                           noise: two renders of this estimator with different seeds at 1280x720 x 10 spp differ by 2.2 % (tools/

@@ -53,15 +53,12 @@
 
 namespace trtd {
 
-// TRT_OCT_NODE_ALIGN: 16 = nodes packed at a stride of 80 B (a node then straddles two 128-B lines 3 times in 8); 128 = one node per line
-// (1.6x the node memory, one line per visit).
-#ifndef TRT_OCT_NODE_ALIGN
-#define TRT_OCT_NODE_ALIGN 16
-#endif
-struct alignas(TRT_OCT_NODE_ALIGN) OctNode {
+// Packed at a stride of 80 B: a node straddles two 128-B lines 3 times in 8.  One node per line (stride 128 B, measured:
+// profiles/r03_ab_oct.txt (6)) fetches fewer lines but takes 1.6x the cache: soup +2.6 %, the meshes -0.6 / -1.2 %, staircase -4.4 %, veach-mis -3.5 %.
+struct OctNode {
     f4 q[5];
 };
-static_assert(sizeof(OctNode) == (TRT_OCT_NODE_ALIGN == 128 ? 128 : 80), "OctNode is five 16-byte words (+ padding to a line)");
+static_assert(sizeof(OctNode) == 80, "OctNode is five 16-byte words");
 
 #define TRT_OCT_MAX_LEAF_TRIS 3u
 

@@ -122,7 +122,7 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
             if (!opts.checkpoint.empty() && readCheckpoint(opts.checkpoint, ck, saved)) {
                 if (ck.width != p.width || ck.height != p.height || ck.spp != p.spp || ck.seed != p.seed || ck.max_depth != p.max_depth)
                     throw std::runtime_error("checkpoint " + opts.checkpoint + " belongs to another render (size, spp, seed or max depth differ)");
-                if (ck.flags != est_flags) throw std::runtime_error("checkpoint " + opts.checkpoint + " was accumulated with another estimator (--fixed-nee / --fixed-pixels differ)");
+                if (ck.flags != est_flags) throw std::runtime_error("checkpoint " + opts.checkpoint + " was accumulated with another estimator (--fixed-nee / --fixed-pixels / --ray-offset differ)");
                 if (ck.n_triangles != flat.c_scene()->n_tris || ck.n_nodes != flat.c_scene()->n_nodes || ck.scene_hash != scene_hash)
                     throw std::runtime_error("checkpoint " + opts.checkpoint + " belongs to another scene (triangles, BVH or scene hash differ)");
                 accum.swap(saved);
