@@ -39,6 +39,7 @@ struct HostScene {
     WideTree wide;
     OctTree oct;
     std::vector<f4> leaf_boxes;
+    std::vector<LightBox> light_boxes;
     int nk = 0;  // node kind the traversal walks: 0 exact 4-wide nodes, 1 compressed 8-wide nodes (TRT_NODE_KIND)
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
@@ -75,6 +76,7 @@ struct HostScene {
         sc.tri_trav = oct.ok ? oct.tri_trav.data() : nullptr;
         sc.n_onodes = (uint32_t)oct.nodes.size();
         leaf_boxes = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris);
+        light_boxes = lightBoxesOf(leaf_boxes, s->tri_mat, s->n_tris, s->lights, s->n_lights);
         sc.leaf_box = leaf_boxes.data();
         sc.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
         nk = (oct.ok && g_node_kind != 0) ? 1 : 0;
@@ -184,7 +186,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
                     const f3 w = cx.beta * contrib;
                     r_sh++;
                     // k_trace_shadow
-                    const Hit sh = hs.nk ? traceClosestOct<OctArrayStack, ArrayStack, false>(hs.sc, rayOrigin(cx, wo), wo, ostk, stk, ni, nt, t_max, fixed, !fixed)
+                    const Hit sh = hs.nk ? traceClosestOct<OctArrayStack, ArrayStack, false>(hs.sc, rayOrigin(cx, wo), wo, ostk, stk, ni, nt, t_max, fixed, !fixed, &hs.light_boxes[li])
                                          : traceClosest<ArrayStack, false, 0>(hs.sc, rayOrigin(cx, wo), wo, stk, ni, nt, t_max, fixed, !fixed);
                     if (fixed ? sh.tri < 0 : (sh.tri >= 0 && (sh.flags >> 8) == (uint32_t)hs.sc.lights[li].mat)) L = L + w;
                 }

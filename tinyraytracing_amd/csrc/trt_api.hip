@@ -87,6 +87,7 @@ struct trt_handle {
     SceneDev sc{};
     std::vector<void*> scene_allocs;
     std::vector<uint32_t> light_mats;
+    std::vector<LightBox> light_boxes;  // per light: the union of the boxes of the leaves that hold its triangles (trt_kernels.h LightBox)
     uint32_t depth = 0;       // stack entries a traversal can need (wide tree), + 1
     uint32_t bvh2_depth = 0;  // depth of the caller's BVH2
     uint32_t shade_tabs = 0;  // which k_shade<TABS> this scene runs
@@ -253,7 +254,7 @@ uint32_t tailGrid(uint32_t n)
 template <bool COUNT, bool PRIMARY>
 void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill, const RaySource& src, f4* hit, uint32_t n, DeviceStats* d_stats, RedoList redo);
 template <bool COUNT>
-void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any, RedoList redo);
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any, RedoList redo, const LightBox& lbox);
 
 struct Timer {
     trt_handle* h;
@@ -294,7 +295,7 @@ struct Timer {
 #define TRT_LAUNCH_CLOSEST(DEPTH, SPILL, IMPL, NK) \
     hipLaunchKernelGGL((k_trace_closest<COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>), g, b, 0, stream, h->sc, src, hit, n, spill, SPILL_STRIDE, d_stats, redo)
 #define TRT_LAUNCH_SHADOW(DEPTH, SPILL, IMPL, NK) \
-    hipLaunchKernelGGL((k_trace_shadow<COUNT, DEPTH, SPILL, IMPL, NK>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any, redo)
+    hipLaunchKernelGGL((k_trace_shadow<COUNT, DEPTH, SPILL, IMPL, NK>), g, b, 0, stream, h->sc, sq, n, light_mat, Lacc, spill, SPILL_STRIDE, d_stats, any, redo, lbox)
 #define TRT_BY_DEPTH(LAUNCH, IMPL, NK)                                       \
     do {                                                                     \
         if (h->depth <= 16) LAUNCH(16, false, IMPL, NK);                     \
@@ -317,7 +318,7 @@ void launchTraceClosest(const trt_handle* h, hipStream_t stream, uint32_t* spill
 }
 
 template <bool COUNT>
-void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any, RedoList redo)
+void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill, const ShadowQueue& sq, uint32_t n, uint32_t light_mat, f4* Lacc, DeviceStats* d_stats, uint32_t any, RedoList redo, const LightBox& lbox)
 {
     const dim3 g(h->traceGrid(n)), b(TRT_TRACE_BLOCK);
     if (h->trace_impl == 0) { TRT_LAUNCH_SHADOW(1, false, 0, 0); return; }
@@ -433,6 +434,9 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         {   // the caller's box of every leaf: a hit in front of its own leaf's box does not count (leafEntry(), trt_path.h)
             const std::vector<f4> lb = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris);
             if (int e = upload(h.get(), lb.data(), lb.size(), &h->sc.leaf_box)) return e;
+            h->light_boxes = lightBoxesOf(lb, s->tri_mat, s->n_tris, s->lights, s->n_lights);
+            if (const char* e = std::getenv("TRT_SHADOW_STOP"))  // 0: all of space as every light's box, i.e. no early end of a shadow ray (A/B)
+                if (std::atoi(e) == 0) h->light_boxes.assign(s->n_lights, LightBox{{-3.0e38f, -3.0e38f, -3.0e38f}, {3.0e38f, 3.0e38f, 3.0e38f}});
         }
         if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
         // The 8-wide compressed nodes (trt_oct.h) for the persistent traversal kernels, when the tree qualifies (nested, finite, leaves
@@ -833,8 +837,8 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
             if (ns > S.n_active) return fail(TRT_EHIP, "internal error: shadow queue longer than its input");
             if (!ns) continue;
             tm.begin(TRT_K_TRACE_SHADOW, S.stream);
-            if (count) launchTraceShadow<true>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee, S.redo);
-            else launchTraceShadow<false>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee, S.redo);
+            if (count) launchTraceShadow<true>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee, S.redo, h->light_boxes[l]);
+            else launchTraceShadow<false>(h, S.stream, S.spill, S.SQ[l], ns, h->light_mats[l], S.Lacc, d_stats, td.fixed_nee, S.redo, h->light_boxes[l]);
             tm.end(S.stream);
             st.launches[TRT_K_TRACE_SHADOW]++;
             st.rays_shadow += ns;

@@ -542,7 +542,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
 __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo, const LightBox& lbox)
 {
     OctLdsStack<DEPTH, SPILL> stk;
     stk.lds = smem + threadIdx.x;
@@ -559,7 +559,8 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
     const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)((w0 + per) < n ? (w0 + per) : n));
 
     constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
-    uint32_t idx = NO_RAY, pid = 0;
+    uint32_t idx = NO_RAY;
+    float stop_t = -TRT_INF;  // parity-mode shadow rays: a hit nearer than this ends the search (LightBox)
     int sp = 0;
     OctGroup ng, tg;
     ng.x = 0u; ng.y = 0u; tg.x = 0u; tg.y = 0u;
@@ -580,7 +581,8 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
         const bool can_fill = next < end;
         if (m_work == 0ull || (m_done != 0ull && (uint32_t)__popcll(can_fill ? m_free : m_done) >= sc.refill_min)) {
             if (done) {
-                const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // the exact reciprocals (R.inv has NaN on the axes the node test leaves out)
+                const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // the exact reciprocals (R.inv stands in 2^40 for an infinite one)
+                const uint32_t pid = SHADOW ? f2u(src.rb[idx].z) : 0u;    // read again here instead of carried through the traversal
                 if (checkedStore<SHADOW, true>(sc, R.o, d, inv, best_t, best_tri, best_flags, idx, pid, hit, sw, light_mat, Lacc, any)) redo.idx[atomicAdd(redo.count, 1u)] = idx;
                 idx = NO_RAY;
             }
@@ -591,12 +593,20 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
                     f4 a, b;
                     fetchRay<PRIMARY>(sc, src, idx, a, b);
                     d = mk3(a.w, b.x, b.y);
-                    if (SHADOW) pid = f2u(b.z);
-                    R = makeOctRay(mk3(a.x, a.y, a.z), d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));
+                    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    R = makeOctRay(mk3(a.x, a.y, a.z), d, inv);
                     best_t = SHADOW ? b.w : TRT_INF; best_tri = -1; best_flags = 0u;
                     sp = 0;
                     ng.x = 0u; ng.y = 0x80000000u;  // the root
                     tg.y = 0u;
+                    if (SHADOW && !any) {
+                        // where the light's triangles can begin (LightBox): a ray that misses the box altogether cannot end on the light —
+                        // no hit there counts — and needs no search at all
+                        float e;
+                        const bool pass = boxTest(lbox.lo[0], lbox.lo[1], lbox.lo[2], lbox.hi[0], lbox.hi[1], lbox.hi[2], R.o, inv, e);
+                        stop_t = trt_leaf_floor(e, sc.leaf_alpha);
+                        if (!pass) ng.y = 0u;
+                    }
                 }
                 const uint32_t taken = (uint32_t)__popcll(m_free);
                 next = (end - next) < taken ? end : next + taken;
@@ -632,6 +642,7 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
                     float t, un, vn, det;
                     if (triTest(T, R.o, d, t, un, vn, det)) octFold(t, f2u(T.c.w), f2u(T.c.z), best_t, best_tri, best_flags);
                 }
+                if (SHADOW && !any && best_tri >= 0 && best_t < stop_t) { tg.y = 0u; ng.y = 0u; sp = 0; }  // occluded for certain (LightBox)
                 if (tg.y == 0u) {
                     if (any && best_tri >= 0) { ng.y = 0u; sp = 0; }  // occlusion test: the first leaf that yields a hit ends the ray
                     adv = (ng.y & 0xFF000000u) == 0u;
@@ -662,10 +673,10 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueue(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
-                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo)
+                                           uint32_t spill_stride, DeviceStats* stats, uint32_t* smem, bool any_flag, RedoList redo, const LightBox& lbox)
 {
     if constexpr (IMPL == 0) traceQueueUniform<SHADOW, COUNT, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, stats, any_flag, reinterpret_cast<f4*>(smem));
-    else if constexpr (NK == 1) traceQueuePersistentOct<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
+    else if constexpr (NK == 1) traceQueuePersistentOct<SHADOW, COUNT, DEPTH, SPILL, PRIMARY>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo, lbox);
     else traceQueuePersistent<SHADOW, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, sw, light_mat, Lacc, spill, spill_stride, stats, smem, any_flag, redo);
 }
 
@@ -676,7 +687,8 @@ __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4*
                                                  uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, RedoList redo)
 {
     __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];  // stack (8-byte entries on the oct tree), or (uniform walk) the candidate queue
-    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false, redo);
+    const LightBox nobox = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    traceQueue<false, COUNT, DEPTH, SPILL, IMPL, PRIMARY, NK>(sc, src, n, hit, nullptr, 0u, nullptr, spill, spill_stride, stats, smem, false, redo, nobox);
 }
 
 // Shadow test of shade() (pathTracing.cpp:51-58): CLOSEST hit, visible iff
@@ -685,14 +697,14 @@ __global__ TRT_TRACE_BOUNDS void k_trace_closest(SceneDev sc, RaySource src, f4*
 // write of Lacc needs no atomic and the sum order is fixed.
 template <bool COUNT, int DEPTH, bool SPILL, int IMPL, int NK>
 __global__ TRT_TRACE_BOUNDS void k_trace_shadow(SceneDev sc, ShadowQueue sq, uint32_t n, uint32_t light_mat, f4* __restrict__ Lacc,
-                                                uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any, RedoList redo)
+                                                uint32_t* __restrict__ spill, uint32_t spill_stride, DeviceStats* stats, uint32_t any, RedoList redo, LightBox lbox)
 {
     __shared__ __attribute__((aligned(16))) uint32_t smem[IMPL == 0 ? TRT_PEND_SLOTS * 4 * TRT_TRACE_BLOCK : (NK == 1 ? 2 : 1) * DEPTH * TRT_TRACE_BLOCK];
     RaySource src;
     src.ra = sq.sa;
     src.rb = sq.sb;
     src.s0 = 0;
-    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false, NK>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u, redo);
+    traceQueue<true, COUNT, DEPTH, SPILL, IMPL, false, NK>(sc, src, n, nullptr, sq.sw, light_mat, Lacc, spill, spill_stride, stats, smem, any != 0u, redo, lbox);
 }
 
 // The exact form of the traversal for the rays a traversal launch put on its redo list (see RedoList): a few blocks, launched

@@ -210,17 +210,40 @@ TRT_HD inline void octFold(float t, uint32_t w, uint32_t fl, float& best_t, int3
     if (take) { best_t = t; best_tri = j; best_flags = fl; }
 }
 
+// Where a light's triangles can begin.  Union of the (caller's, exact) boxes of the leaves that hold the triangles of one light's
+// material, per shadow launch.  In parity mode a shadow ray is "visible" iff its CLOSEST counting hit carries that material (Q5).
+// Every hit on such a triangle that counts lies at or behind floor(entry of its leaf's box) (the leaf-box rule, trt_path.h), and the
+// entry of a box that contains the leaf's is no later (subtraction, multiplication, min and max are monotone; where a NaN of 0 * inf
+// makes the two tests differ, the leaf's fails and none of its hits count), nor is its floor (trt_leaf_floor is monotone).  So once the
+// search holds ANY hit nearer than stop = floor(entry of this box), the closest hit is not on the light: the ray is occluded and the
+// search ends — provided that hit counts, which the store checks as for every result (octResultCounts; otherwise the exact form runs).
+// A ray that does not pass this box at all has no counting hit on the light and needs no search.
+struct LightBox {
+    float lo[3], hi[3];
+};
+
 // Stack of the oct traversal: one 8-byte group per level.  push(sp, g) / pop(sp).
 // Per-lane closest-hit search on the oct tree (the order of operations of the wave driver in trt_kernels.h, one lane): returns
 // the hit WITHOUT the final check (see traceClosestOct).  Same `t_init` / `any` / `redo` meaning as traceClosestPass.
 template <class Stack, bool COUNT>
-TRT_HD inline Hit traceOctPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init, bool any, bool redo)
+TRT_HD inline Hit traceOctPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init, bool any, bool redo,
+                               const LightBox* lbox = nullptr)
 {
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const OctRay R = makeOctRay(o, d, inv);
     float best_t = t_init;
     int32_t best_tri = -1;
     uint32_t best_flags = 0u;
+    float stop_t = -TRT_INF;
+    if (lbox && !any) {
+        float e;
+        if (!boxTest(lbox->lo[0], lbox->lo[1], lbox->lo[2], lbox->hi[0], lbox->hi[1], lbox->hi[2], o, inv, e)) {
+            Hit h;
+            h.t = best_t; h.tri = -1; h.u = 0.f; h.v = 0.f; h.flags = 0u;
+            return h;
+        }
+        stop_t = trt_leaf_floor(e, sc.leaf_alpha);
+    }
     for (;;) {  // once; twice when `redo` and nothing lies in front of t_init
         int sp = 0;
         OctGroup ng, tg;
@@ -246,7 +269,7 @@ TRT_HD inline Hit traceOctPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
                 float t, un, vn, det;
                 if (triTest(T, o, d, t, un, vn, det)) octFold(t, f2u(T.c.w), f2u(T.c.z), best_t, best_tri, best_flags);
             }
-            if (any && best_tri >= 0) { stop = true; break; }
+            if (best_tri >= 0 && (any || best_t < stop_t)) { stop = true; break; }
             if (!(ng.y & 0xFF000000u)) {
                 if (sp == 0) break;
                 ng = stk.pop(--sp);
@@ -279,9 +302,9 @@ TRT_HD inline bool octResultCounts(const SceneDev& sc, float t, int32_t tri, f3 
 // `StackW` is the 32-bit reference stack of traceClosestPass.
 template <class StackO, class StackW, bool COUNT>
 TRT_HD inline Hit traceClosestOct(const SceneDev& sc, f3 o, f3 d, StackO& stk, StackW& stkw, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF,
-                                  bool any = false, bool redo = false)
+                                  bool any = false, bool redo = false, const LightBox* lbox = nullptr)
 {
-    const Hit h = traceOctPass<StackO, COUNT>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo);
+    const Hit h = traceOctPass<StackO, COUNT>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo, lbox);
     if (octResultCounts(sc, h.t, h.tri, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) return h;
     return traceClosestPass<StackW, COUNT, 0, true>(sc, o, d, stkw, n_inner, n_tri, t_init, any, redo);
 }

@@ -232,4 +232,21 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
     return t;
 }
 
+// Per light: the union of the boxes of the leaves that hold the triangles of its material (LightBox, trt_oct.h); a light without
+// triangles gets an inverted box, which no ray passes.  `lb` = leafBoxesOf().
+inline std::vector<LightBox> lightBoxesOf(const std::vector<f4>& lb, const int32_t* tri_mat, uint32_t n_tris, const trt_light* lights, uint32_t n_lights)
+{
+    std::vector<LightBox> out(n_lights, LightBox{{3.0e38f, 3.0e38f, 3.0e38f}, {-3.0e38f, -3.0e38f, -3.0e38f}});
+    for (uint32_t l = 0; l < n_lights; ++l) {
+        LightBox& B = out[l];
+        for (uint32_t i = 0; i < n_tris; ++i) {
+            if (tri_mat[i] != lights[l].mat) continue;
+            const f4 a = lb[2 * (size_t)i], b = lb[2 * (size_t)i + 1];
+            B.lo[0] = std::fmin(B.lo[0], a.x); B.lo[1] = std::fmin(B.lo[1], a.y); B.lo[2] = std::fmin(B.lo[2], a.z);
+            B.hi[0] = std::fmax(B.hi[0], a.w); B.hi[1] = std::fmax(B.hi[1], b.x); B.hi[2] = std::fmax(B.hi[2], b.y);
+        }
+    }
+    return out;
+}
+
 }  // namespace trtd
