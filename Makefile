@@ -54,7 +54,7 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) $(OUT)/li
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options
-VARIANTS := w8=-DTRT_TRACE_MINWAVES=8
+VARIANTS := w8=-DTRT_TRACE_MINWAVES=8 short=-DTRT_PROBE_SHORT_RECORDS
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
 	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \

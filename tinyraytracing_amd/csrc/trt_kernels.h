@@ -877,6 +877,17 @@ struct RowsShade {
 // instantiation.  A compile-time choice so that every table access is a plain LDS (ds_read) or global load: behind a
 // run-time choice the pointers are generic, the accesses FLAT, and each of them waits for vmcnt(0) — i.e. for the ray
 // stores issued before it — as well as for the LDS.
+// Performance probe only (make variants, `short`): the weight and throughput records stored as 8 bytes instead of 16 — WRONG images, same
+// instruction stream otherwise — to measure what a record diet of k_shade could buy at most (profiles/r03_ab_oct.txt (8)).
+#ifdef TRT_PROBE_SHORT_RECORDS
+#define TRT_STORE_W(arr, slot, x, y, z) (reinterpret_cast<float2*>(arr)[slot] = make_float2((x), (y) + (z)))
+#define TRT_STORE_BT(arr, slot, v) (reinterpret_cast<float2*>(arr)[slot] = make_float2((v).x + (v).w, (v).y + (v).z))
+#define TRT_LOAD_BT(arr, i, bt) { const float2 q_ = reinterpret_cast<const float2*>(arr)[i]; (bt) = mk4(q_.x, q_.y, q_.y, 0.0f); }
+#else
+#define TRT_STORE_W(arr, slot, x, y, z) ((arr)[slot] = mk4((x), (y), (z), 0.0f))
+#define TRT_STORE_BT(arr, slot, v) ((arr)[slot] = (v))
+#define TRT_LOAD_BT(arr, i, bt) ((bt) = (arr)[i])
+#endif
 template <uint32_t TABS>
 __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
 {
@@ -912,7 +923,7 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         hit4 = mk4(TRT_INF, u2f(0xFFFFFFFFu), 0.0f, 0.0f); ra = mk4(0, 0, 0, 0); rb = ra; bt = mk4(1.0f, 1.0f, 1.0f, 0.0f);
         if (i < A.n) {
             hit4 = A.hit[i];
-            if (!A.primary) { ra = A.qin.ra[i]; rb = A.qin.rb[i]; bt = A.qin.bt[i]; }
+            if (!A.primary) { ra = A.qin.ra[i]; rb = A.qin.rb[i]; TRT_LOAD_BT(A.qin.bt, i, bt); }
         }
     };
 #if TRT_SHADE_PIPE
@@ -991,7 +1002,7 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
                 const f3 so = rayOrigin(c, pend_wo);  // Q6: the hit point itself unless TRT_FLAG_RAY_OFFSET
                 A.sq[pend_li].sa[slot] = mk4(so.x, so.y, so.z, pend_wo.x);
                 A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
-                A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
+                TRT_STORE_W(A.sq[pend_li].sw, slot, pend_w.x, pend_w.y, pend_w.z);
             }
             pend_s = s; pend_emit = emit; pend_rank = rank; pend_li = li; pend_wo = wo; pend_w = c.beta * contrib; pend_tmax = t_max;
         }
@@ -1020,7 +1031,7 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             const f3 so = rayOrigin(c, pend_wo);
             A.sq[pend_li].sa[slot] = mk4(so.x, so.y, so.z, pend_wo.x);
             A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
-            A.sq[pend_li].sw[slot] = mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f);
+            TRT_STORE_W(A.sq[pend_li].sw, slot, pend_w.x, pend_w.y, pend_w.z);
         }
         f4 nra = mk4(0, 0, 0, 0), nrb = nra, nbt = nra;
         if (emit_next) shadeNextFinish(c, plan, nra, nrb, nbt);
@@ -1034,13 +1045,13 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
             const f3 so = rayOrigin(c, wo_s);
             A.sq[nl - 1u].sa[slot] = mk4(so.x, so.y, so.z, wo_s.x);
             A.sq[nl - 1u].sb[slot] = mk4(wo_s.y, wo_s.z, u2f(c.pid), tmax_s);
-            A.sq[nl - 1u].sw[slot] = mk4(w_s.x, w_s.y, w_s.z, 0.0f);
+            TRT_STORE_W(A.sq[nl - 1u].sw, slot, w_s.x, w_s.y, w_s.z);
         }
         if (emit_next) {
             const uint32_t slot = s2[TRT_SHADE_BLOCK / 64] + s2[threadIdx.x >> 6] + rank_next;
             A.qout.ra[slot] = nra;
             A.qout.rb[slot] = nrb;
-            A.qout.bt[slot] = nbt;
+            TRT_STORE_BT(A.qout.bt, slot, nbt);
         }
     }
     __syncthreads();
