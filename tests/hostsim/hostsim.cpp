@@ -119,6 +119,31 @@ extern "C" int hostsim_compressible(const trt_scene* s)
     for (uint32_t i = 0; i < s->n_tris; ++i) isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, s->tri_mat[i], s->materials[s->tri_mat[i]].is_emissive != 0);
     return buildOct(s->nodes, s->n_nodes, s->n_tris, isect.data()).ok ? 1 : 0;
 }
+// FNV-1a hashes of the trees the collapses build with `threads` host threads: [0] 4-wide (dynamic programme), [1] 4-wide (greedy),
+// [2] 8-wide nodes, [3] their triangle records, [4..6] stack need / dropped boxes / levels — the results must not depend on the thread count.
+extern "C" int hostsim_tree_hashes(const trt_scene* s, unsigned threads, uint64_t out[8])
+{
+    auto fnv = [](const void* p, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        const uint8_t* b = static_cast<const uint8_t*>(p);
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+        return h;
+    };
+    std::vector<TriIsect> isect(s->n_tris);
+    for (uint32_t i = 0; i < s->n_tris; ++i) isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, s->tri_mat[i], s->materials[s->tri_mat[i]].is_emissive != 0);
+    const WideTree a = collapseBvh(s->nodes, s->n_nodes, threads), b = collapseBvhGreedy(s->nodes, s->n_nodes, threads);
+    const OctTree t = buildOct(s->nodes, s->n_nodes, s->n_tris, isect.data(), threads);
+    const std::vector<f4> lb = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris, threads);
+    out[0] = fnv(a.nodes.data(), a.nodes.size() * sizeof(WideNode));
+    out[1] = fnv(b.nodes.data(), b.nodes.size() * sizeof(WideNode));
+    out[2] = t.ok ? fnv(t.nodes.data(), t.nodes.size() * sizeof(OctNode)) : 0;
+    out[3] = t.ok ? fnv(t.tri_trav.data(), t.tri_trav.size() * sizeof(TriIsect)) : 0;
+    out[4] = ((uint64_t)a.stack_need << 32) | b.stack_need;
+    out[5] = a.dropped * 1000003ull + b.dropped;
+    out[6] = t.levels;
+    out[7] = fnv(lb.data(), lb.size() * sizeof(f4));
+    return 0;
+}
 // nodes / levels of the oct tree (0 when it cannot be built)
 extern "C" int hostsim_oct_info(const trt_scene* s, uint64_t out[3])
 {

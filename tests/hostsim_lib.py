@@ -24,6 +24,7 @@ def lib():
         L.hostsim_oct_fallbacks.restype = C.c_uint64
         L.hostsim_oct_fallbacks.argtypes = [C.POINTER(SceneFlat), C.c_uint64, fp, fp]
         L.hostsim_oct_info.argtypes = [C.POINTER(SceneFlat), C.POINTER(C.c_uint64)]
+        L.hostsim_tree_hashes.argtypes = [C.POINTER(SceneFlat), C.c_uint, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -84,3 +85,10 @@ def oct_info(flat):
     """(nodes, levels, triangle records) of the oct tree, or None when the tree does not qualify."""
     out = (C.c_uint64 * 3)()
     return None if lib().hostsim_oct_info(flat, out) else tuple(int(x) for x in out)
+
+
+def tree_hashes(flat, threads):
+    """Hashes of the 4-wide trees (both collapses), the 8-wide tree, its triangle records and the leaf boxes, built with `threads` host threads."""
+    out = (C.c_uint64 * 8)()
+    assert lib().hostsim_tree_hashes(flat, int(threads), out) == 0
+    return [int(x) for x in out]

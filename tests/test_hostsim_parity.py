@@ -282,3 +282,16 @@ def test_grazing_rays_culled_equals_unculled(name):
     th, trih, uvh, _ = H.trace(sc.flat, o, d)
     to, trio, uvo = O.trace(sc.flat, o, d)
     assert np.array_equal(trih, trio) and np.array_equal(th, to) and np.array_equal(uvh, uvo)
+
+
+@pytest.mark.parametrize("name,kw", [("veach-mis", {}), ("staircase", {}), ("soup", {"n": 60000}), ("blob", {"n": 150000})])
+def test_the_collapses_do_not_depend_on_the_number_of_host_threads(name, kw):
+    """trt_create collapses the caller's tree with several host threads (trt_wide.h `par`: subtrees of a cut of the binary tree for the
+    dynamic programmes, blocks placed where the sequential walk puts them for the 4-wide nodes, level by level for the 8-wide ones): the
+    4-wide trees of both collapses, the 8-wide nodes, their triangle records and the leaf boxes have the same bytes for 1, 2, 3 and 7 threads."""
+    s = T.Scene.named(name, 64, 64, **kw)
+    ref = H.tree_hashes(s.flat, 1)
+    assert ref[2] != 0 and ref[6] > 1, "the scene qualifies for the 8-wide nodes"
+    for threads in (2, 3, 7):
+        assert H.tree_hashes(s.flat, threads) == ref, threads
+    s.close()

@@ -333,23 +333,47 @@ void launchTraceShadow(const trt_handle* h, hipStream_t stream, uint32_t* spill,
 
 }  // namespace
 
-extern "C" {
+namespace {
+// Everything trt_create derives from the caller's scene on the host — checks, triangle records, the 4-wide and 8-wide collapses, the
+// leaf and light boxes, the tuning read from the environment — independent of the device: built once (host threads: trt_wide.h `par`,
+// TRT_HOST_THREADS), uploaded to every device of a group (trt_group_create).
+struct SceneImage {
+    const trt_scene* s = nullptr;
+    unsigned threads = 1;
+    bool dbg = false;
+    uint32_t bvh2_depth = 0;
+    int trace_impl = 3;
+    int node_kind = 0;
+    std::vector<TriIsect> isect;
+    std::vector<TriShade> shade;
+    WideTree wide;
+    OctTree oct;
+    std::vector<f4> leaf_boxes;
+    std::vector<LightBox> light_boxes;
+    std::vector<MaterialDev> mats;
+    std::vector<LightDev> lights;
+    std::vector<LightTriDev> ltris;
+    std::vector<float> cum;
+    bool cum_monotone = true;
+    std::vector<TextureDev> tex;
+    std::vector<uint8_t> tex_bytes;
+    float leaf_alpha = 0.0f;
+};
 
-const char* trt_last_error(void) { return g_err.c_str(); }
-int trt_abi_version(void) { return TRT_ABI_VERSION; }
+struct Lap {  // TRT_DEBUG: where the start-up time of a big scene goes (tools/create_cost.py)
+    bool on;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(const char* what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "trt_create: %-32s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
-int trt_rows_selected(const trt_params* p)
+int buildSceneImage(const trt_scene* s, SceneImage& im)
 {
-    if (!p) return -1;
-    int n = 0;
-    for (int y = p->y0; y < p->y1; ++y) n += rowSelected(p, y) ? 1 : 0;
-    return n;
-}
-
-int trt_create(const trt_scene* s, int device, trt_handle** out)
-{
-    if (!s || !out) return fail(TRT_EINVAL, "trt_create: null argument");
-    *out = nullptr;
     if (s->n_nodes < 1 || !s->nodes) return fail(TRT_EINVAL, "scene needs at least the root node");
     if (s->n_tris > TRT_MAX_TRIS) return fail(TRT_EINVAL, "too many triangles");
     if (s->n_tris && (!s->tri_v || !s->tri_vn || !s->tri_vt || !s->tri_mat)) return fail(TRT_EINVAL, "null triangle arrays");
@@ -367,9 +391,93 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     }
     for (uint32_t i = 0; i < s->n_textures; ++i)
         if (s->textures[i].width < 1 || s->textures[i].height < 1 || !s->textures[i].rgb) return fail(TRT_EINVAL, "empty texture");
-    uint32_t depth = 0;
-    if (int e = validateBvh(s, &depth)) return e;
+    im.s = s;
+    im.dbg = std::getenv("TRT_DEBUG") != nullptr;
+    im.threads = par::defaultThreads();
+    if (const char* e = std::getenv("TRT_HOST_THREADS")) im.threads = (unsigned)std::min(256, std::max(1, std::atoi(e)));
+    Lap lap{im.dbg};
+    if (int e = validateBvh(s, &im.bvh2_depth)) return e;
+    lap("checks, validateBvh");
 
+    // the wave-uniform walk needs a 32-bit reach mask, and it evaluates the nodes in index order: every inner child must
+    // come after its parent (all builders here emit parents first; a caller's tree that does not is walked per lane)
+    bool tiny = s->n_nodes <= 32 && s->n_tris <= 64;
+    for (uint32_t n = 0; tiny && n < s->n_nodes; ++n) {
+        const uint32_t ch[2] = {s->nodes[n].child0, s->nodes[n].child1};
+        for (uint32_t c : ch)
+            if (!(c & TRT_LEAF_BIT) && c <= n) tiny = false;
+    }
+    im.trace_impl = tiny ? 0 : 3;
+    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { if (std::atoi(e) == 3) im.trace_impl = 3; }  // tests: the per-lane driver on a tiny tree too
+
+    // 48-B intersection records and 64-B shading records
+    im.isect.resize(s->n_tris);
+    im.shade.resize(s->n_tris);
+    par::forRange(s->n_tris, im.threads, 65536, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            const int32_t mat = s->tri_mat[i];
+            im.isect[i] = makeTriIsect(s->tri_v + i * 9, mat, s->materials[mat].is_emissive != 0);
+            std::memcpy(im.shade[i].vn, s->tri_vn + i * 9, sizeof(float) * 9);
+            std::memcpy(im.shade[i].vt, s->tri_vt + i * 6, sizeof(float) * 6);
+            im.shade[i].mat = mat;
+        }
+    });
+    lap("triangle records");
+    {   // the 4-wide collapse every per-lane traversal can walk; its stack bound sizes the LDS stack / the spill area
+        bool greedy = s->n_tris > 4000000u;  // measured: trt_wide.h
+        if (const char* e = std::getenv("TRT_WIDE_GREEDY")) greedy = std::atoi(e) != 0;
+        im.wide = greedy ? collapseBvhGreedy(s->nodes, s->n_nodes, im.threads) : collapseBvh(s->nodes, s->n_nodes, im.threads);
+        lap("4-wide collapse");
+    }
+    // the caller's box of every leaf: a hit in front of its own leaf's box does not count (leafEntry(), trt_path.h)
+    im.leaf_boxes = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris, im.threads);
+    im.light_boxes = lightBoxesOf(im.leaf_boxes, s->tri_mat, s->n_tris, s->lights, s->n_lights);
+    if (const char* e = std::getenv("TRT_SHADOW_STOP"))  // 0: all of space as every light's box, i.e. no early end of a shadow ray (A/B)
+        if (std::atoi(e) == 0) im.light_boxes.assign(s->n_lights, LightBox{{-3.0e38f, -3.0e38f, -3.0e38f}, {3.0e38f, 3.0e38f, 3.0e38f}});
+    im.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
+    lap("leaf boxes, light boxes");
+    // The 8-wide compressed nodes (trt_oct.h) for the persistent traversal kernels, when the tree qualifies (nested, finite, leaves
+    // of <= 3 triangles): TRT_NODE_KIND=0/1 in the environment forces either kind (A/B runs, tests).
+    bool want_oct = im.trace_impl != 0 && TRT_DEFAULT_NODE_KIND == 1;
+    if (const char* e = std::getenv("TRT_NODE_KIND")) want_oct = im.trace_impl != 0 && std::atoi(e) == 1;
+    if (want_oct) {
+        im.oct = buildOct(s->nodes, s->n_nodes, s->n_tris, im.isect.data(), im.threads);
+        im.node_kind = im.oct.ok ? 1 : 0;
+        lap("8-wide collapse");
+        if (im.dbg) std::fprintf(stderr, "trt_create: oct tree %s (%s): %zu nodes, %u levels\n", im.oct.ok ? "built" : "not built", im.oct.why, im.oct.nodes.size(), im.oct.levels);
+    }
+    if (im.dbg) std::fprintf(stderr, "trt_create: %zu wide nodes, node kind %d, stack need %u, %u host threads\n", im.wide.nodes.size(), im.node_kind, im.wide.stack_need, im.threads);
+
+    im.mats.resize(s->n_materials);
+    for (uint32_t i = 0; i < s->n_materials; ++i) im.mats[i] = makeMaterialDev(s->materials[i]);
+    im.lights.resize(s->n_lights);
+    for (uint32_t i = 0; i < s->n_lights; ++i) im.lights[i] = makeLightDev(s->lights[i]);
+    im.ltris.resize(s->n_light_tris);
+    for (uint32_t i = 0; i < s->n_light_tris; ++i) im.ltris[i] = makeLightTriDev(s->light_tris[i]);
+    // packed CDF for the bisection in lightSample; only when every light's CDF is non-decreasing and NaN-free
+    im.cum.resize(s->n_light_tris);
+    for (uint32_t k = 0; k < s->n_light_tris; ++k) im.cum[k] = s->light_tris[k].cum_area;
+    for (uint32_t l = 0; l < s->n_lights; ++l)
+        for (uint32_t k = 0; k < s->lights[l].tri_count; ++k) {
+            const float c = im.cum[s->lights[l].tri_first + k];
+            if (!(c == c) || (k && c < im.cum[s->lights[l].tri_first + k - 1])) im.cum_monotone = false;
+        }
+    im.tex.resize(s->n_textures);
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        im.tex[i].width = s->textures[i].width;
+        im.tex[i].height = s->textures[i].height;
+        im.tex[i].offset = im.tex_bytes.size();
+        const size_t nb = (size_t)im.tex[i].width * im.tex[i].height * 3;
+        im.tex_bytes.insert(im.tex_bytes.end(), s->textures[i].rgb, s->textures[i].rgb + nb);
+    }
+    return TRT_OK;
+}
+
+// The device half of trt_create: a handle on `device` from the host image (thread-safe against other devices' calls: touches only
+// the handle, the image read-only and this thread's HIP device).
+int createOnDevice(const SceneImage& im, int device, trt_handle** out)
+{
+    const trt_scene* s = im.s;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(TRT_ENODEV, "no HIP device");
     if (device < 0 || device >= ndev) return fail(TRT_ENODEV, "device ordinal out of range");
@@ -378,9 +486,10 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
     HIPC(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(TRT_ENODEV, std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName);
 
+    Lap lap{im.dbg};
     std::unique_ptr<trt_handle> h(new trt_handle);
     h->device = device;
-    h->bvh2_depth = depth;
+    h->bvh2_depth = im.bvh2_depth;
     if (const char* e = std::getenv("TRT_TAIL_N")) h->tail_n = (uint32_t)std::strtoul(e, nullptr, 10);
     h->sc.refill_min = s->n_tris <= 200000u ? 48u : 32u;
     // a triangle step costs about half a node step: deep trees run it already when 2 lanes at nodes face 3 at leaves
@@ -392,118 +501,43 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
         if (std::sscanf(e, "%u:%u", &a, &b) == 2 && a > 0 && b > 0 && a < 1024 && b < 1024) { h->sc.sched_in_w = a; h->sc.sched_lf_w = b; }
     }
     if (const char* e = std::getenv("TRT_REFILL_MIN")) h->sc.refill_min = std::min(64u, std::max(1u, (uint32_t)std::strtoul(e, nullptr, 10)));
-    if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: refill_min %u tail_n %u\n", h->sc.refill_min, h->tail_n);
+    if (im.dbg) std::fprintf(stderr, "trt_create: refill_min %u tail_n %u\n", h->sc.refill_min, h->tail_n);
     if (const char* e = std::getenv("TRT_TRACE_RPW")) h->rays_per_wave = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TRT_TRACE_FILLB")) h->fill_blocks = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TRT_TRACE_MAXB")) h->max_blocks = std::max(8u, (uint32_t)std::strtoul(e, nullptr, 10));
-    // shallow trees (everything L1-resident, a dozen steps per ray): the static driver has the least overhead;
-    // deeper ones gain more from lane refill and step scheduling (measured: DESIGN.md)
-    // the wave-uniform walk needs a 32-bit reach mask, and it evaluates the nodes in index order: every inner child must
-    // come after its parent (all builders here emit parents first; a caller's tree that does not is walked per lane)
-    bool tiny = s->n_nodes <= 32 && s->n_tris <= 64;
-    for (uint32_t n = 0; tiny && n < s->n_nodes; ++n) {
-        const uint32_t ch[2] = {s->nodes[n].child0, s->nodes[n].child1};
-        for (uint32_t c : ch)
-            if (!(c & TRT_LEAF_BIT) && c <= n) tiny = false;
-    }
-    h->trace_impl = tiny ? 0 : 3;
-    if (const char* e = std::getenv("TRT_TRACE_IMPL")) { if (std::atoi(e) == 3) h->trace_impl = 3; }  // tests: the per-lane driver on a tiny tree too
+    h->trace_impl = im.trace_impl;
+    h->node_kind = im.node_kind;
+    h->oct_levels = im.oct.levels;
+    h->depth = im.wide.stack_need + 1;
+    h->light_boxes = im.light_boxes;
 
-    {   // 48-B intersection records and 64-B shading records
-        std::vector<TriIsect> isect(s->n_tris);
-        std::vector<TriShade> shade(s->n_tris);
-        for (uint32_t i = 0; i < s->n_tris; ++i) {
-            const int32_t mat = s->tri_mat[i];
-            isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, mat, s->materials[mat].is_emissive != 0);
-            std::memcpy(shade[i].vn, s->tri_vn + (size_t)i * 9, sizeof(float) * 9);
-            std::memcpy(shade[i].vt, s->tri_vt + (size_t)i * 6, sizeof(float) * 6);
-            shade[i].mat = mat;
-        }
-        if (int e = upload(h.get(), isect.data(), isect.size(), &h->sc.tri_isect)) return e;
-        if (int e = upload(h.get(), shade.data(), shade.size(), &h->sc.tri_shade)) return e;
-    }
+    if (int e = upload(h.get(), im.isect.data(), im.isect.size(), &h->sc.tri_isect)) return e;
+    if (int e = upload(h.get(), im.shade.data(), im.shade.size(), &h->sc.tri_shade)) return e;
     if (int e = upload(h.get(), s->nodes, (size_t)s->n_nodes, &h->sc.nodes)) return e;
-    {   // the 4-wide collapse every per-lane traversal walks; its stack bound sizes the LDS stack / the spill area
-        bool greedy = s->n_tris > 4000000u;  // measured: trt_wide.h
-        if (const char* e = std::getenv("TRT_WIDE_GREEDY")) greedy = std::atoi(e) != 0;
-        const WideTree wide = greedy ? collapseBvhGreedy(s->nodes, s->n_nodes) : collapseBvh(s->nodes, s->n_nodes);
-        h->sc.n_wnodes = (uint32_t)wide.nodes.size();
-        h->depth = wide.stack_need + 1;
-        h->sc.wnodes = nullptr;
-        h->sc.leaf_box = nullptr;
-        {   // the caller's box of every leaf: a hit in front of its own leaf's box does not count (leafEntry(), trt_path.h)
-            const std::vector<f4> lb = leafBoxesOf(s->nodes, s->n_nodes, s->n_tris);
-            if (int e = upload(h.get(), lb.data(), lb.size(), &h->sc.leaf_box)) return e;
-            h->light_boxes = lightBoxesOf(lb, s->tri_mat, s->n_tris, s->lights, s->n_lights);
-            if (const char* e = std::getenv("TRT_SHADOW_STOP"))  // 0: all of space as every light's box, i.e. no early end of a shadow ray (A/B)
-                if (std::atoi(e) == 0) h->light_boxes.assign(s->n_lights, LightBox{{-3.0e38f, -3.0e38f, -3.0e38f}, {3.0e38f, 3.0e38f, 3.0e38f}});
-        }
-        if (int e = upload(h.get(), wide.nodes.data(), wide.nodes.size(), &h->sc.wnodes)) return e;
-        // The 8-wide compressed nodes (trt_oct.h) for the persistent traversal kernels, when the tree qualifies (nested, finite, leaves
-        // of <= 3 triangles): TRT_NODE_KIND=0/1 in the environment forces either kind (A/B runs, tests).
-        h->sc.onodes = nullptr;
-        h->sc.tri_trav = nullptr;
-        bool want_oct = h->trace_impl != 0 && TRT_DEFAULT_NODE_KIND == 1;
-        if (const char* e = std::getenv("TRT_NODE_KIND")) want_oct = h->trace_impl != 0 && std::atoi(e) == 1;
-        if (want_oct) {
-            std::vector<TriIsect> isect(s->n_tris);
-            for (uint32_t i = 0; i < s->n_tris; ++i) isect[i] = makeTriIsect(s->tri_v + (size_t)i * 9, s->tri_mat[i], s->materials[s->tri_mat[i]].is_emissive != 0);
-            const OctTree oct = buildOct(s->nodes, s->n_nodes, s->n_tris, isect.data());
-            if (oct.ok) {
-                h->node_kind = 1;
-                h->oct_levels = oct.levels;
-                h->sc.n_onodes = (uint32_t)oct.nodes.size();
-                if (int e = upload(h.get(), oct.nodes.data(), oct.nodes.size(), &h->sc.onodes)) return e;
-                if (int e = upload(h.get(), oct.tri_trav.data(), oct.tri_trav.size(), &h->sc.tri_trav)) return e;
-            }
-            if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: oct tree %s (%s): %zu nodes, %u levels\n", oct.ok ? "built" : "not built", oct.why, oct.nodes.size(), oct.levels);
-        }
-        if (std::getenv("TRT_DEBUG")) std::fprintf(stderr, "trt_create: %zu wide nodes, node kind %d, stack need %u\n", wide.nodes.size(), h->node_kind, wide.stack_need);
+    h->sc.n_wnodes = (uint32_t)im.wide.nodes.size();
+    if (int e = upload(h.get(), im.leaf_boxes.data(), im.leaf_boxes.size(), &h->sc.leaf_box)) return e;
+    if (int e = upload(h.get(), im.wide.nodes.data(), im.wide.nodes.size(), &h->sc.wnodes)) return e;
+    h->sc.onodes = nullptr;
+    h->sc.tri_trav = nullptr;
+    if (im.node_kind == 1) {
+        h->sc.n_onodes = (uint32_t)im.oct.nodes.size();
+        if (int e = upload(h.get(), im.oct.nodes.data(), im.oct.nodes.size(), &h->sc.onodes)) return e;
+        if (int e = upload(h.get(), im.oct.tri_trav.data(), im.oct.tri_trav.size(), &h->sc.tri_trav)) return e;
     }
-    {
-        std::vector<MaterialDev> mats(s->n_materials);
-        for (uint32_t i = 0; i < s->n_materials; ++i) mats[i] = makeMaterialDev(s->materials[i]);
-        if (int e = upload(h.get(), mats.data(), mats.size(), &h->sc.materials)) return e;
-    }
-    {
-        std::vector<LightDev> lights(s->n_lights);
-        for (uint32_t i = 0; i < s->n_lights; ++i) lights[i] = makeLightDev(s->lights[i]);
-        std::vector<LightTriDev> ltris(s->n_light_tris);
-        for (uint32_t i = 0; i < s->n_light_tris; ++i) ltris[i] = makeLightTriDev(s->light_tris[i]);
-        if (int e = upload(h.get(), lights.data(), lights.size(), &h->sc.lights)) return e;
-        if (int e = upload(h.get(), ltris.data(), ltris.size(), &h->sc.light_tris)) return e;
-    }
-    {   // packed CDF for the bisection in lightSample; only when every light's CDF is non-decreasing and NaN-free
-        std::vector<float> cum(s->n_light_tris);
-        bool mono = true;
-        for (uint32_t k = 0; k < s->n_light_tris; ++k) cum[k] = s->light_tris[k].cum_area;
-        for (uint32_t l = 0; l < s->n_lights; ++l)
-            for (uint32_t k = 0; k < s->lights[l].tri_count; ++k) {
-                const float c = cum[s->lights[l].tri_first + k];
-                if (!(c == c) || (k && c < cum[s->lights[l].tri_first + k - 1])) mono = false;
-            }
-        h->sc.light_cum = nullptr;
-        if (mono)
-            if (int e = upload(h.get(), cum.data(), cum.size(), &h->sc.light_cum)) return e;
-    }
-    {
-        std::vector<TextureDev> tex(s->n_textures);
-        std::vector<uint8_t> bytes;
-        for (uint32_t i = 0; i < s->n_textures; ++i) {
-            tex[i].width = s->textures[i].width;
-            tex[i].height = s->textures[i].height;
-            tex[i].offset = bytes.size();
-            const size_t nb = (size_t)tex[i].width * tex[i].height * 3;
-            bytes.insert(bytes.end(), s->textures[i].rgb, s->textures[i].rgb + nb);
-        }
-        if (int e = upload(h.get(), tex.data(), tex.size(), &h->sc.textures)) return e;
-        if (int e = upload(h.get(), bytes.data(), bytes.size(), &h->sc.tex_bytes)) return e;
-    }
+    if (int e = upload(h.get(), im.mats.data(), im.mats.size(), &h->sc.materials)) return e;
+    if (int e = upload(h.get(), im.lights.data(), im.lights.size(), &h->sc.lights)) return e;
+    if (int e = upload(h.get(), im.ltris.data(), im.ltris.size(), &h->sc.light_tris)) return e;
+    h->sc.light_cum = nullptr;
+    if (im.cum_monotone)
+        if (int e = upload(h.get(), im.cum.data(), im.cum.size(), &h->sc.light_cum)) return e;
+    if (int e = upload(h.get(), im.tex.data(), im.tex.size(), &h->sc.textures)) return e;
+    if (int e = upload(h.get(), im.tex_bytes.data(), im.tex_bytes.size(), &h->sc.tex_bytes)) return e;
+    lap("uploads");
     h->sc.n_tris = s->n_tris;
     h->sc.n_nodes = s->n_nodes;
     h->sc.n_lights = s->n_lights;
     h->sc.light0_area = s->n_lights ? s->lights[0].area : 0.0f;
-    h->sc.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
+    h->sc.leaf_alpha = im.leaf_alpha;
     h->sc.cam = s->camera;
     for (uint32_t i = 0; i < s->n_lights; ++i) h->light_mats.push_back((uint32_t)s->lights[i].mat);
     {   // which small tables k_shade copies into LDS: in this order while they fit (uploads are padded to 16 B)
@@ -558,6 +592,29 @@ int trt_create(const trt_scene* s, int device, trt_handle** out)
 
     *out = h.release();
     return TRT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* trt_last_error(void) { return g_err.c_str(); }
+int trt_abi_version(void) { return TRT_ABI_VERSION; }
+
+int trt_rows_selected(const trt_params* p)
+{
+    if (!p) return -1;
+    int n = 0;
+    for (int y = p->y0; y < p->y1; ++y) n += rowSelected(p, y) ? 1 : 0;
+    return n;
+}
+
+int trt_create(const trt_scene* s, int device, trt_handle** out)
+{
+    if (!s || !out) return fail(TRT_EINVAL, "trt_create: null argument");
+    *out = nullptr;
+    SceneImage im;
+    if (int e = buildSceneImage(s, im)) return e;
+    return createOnDevice(im, device, out);
 }
 
 void trt_destroy(trt_handle* h)
@@ -1184,11 +1241,24 @@ int trt_group_create(const trt_scene* scene, int n_devices, const int* devices, 
             if (devices[a] == devices[b]) distinct = false;
     const char* force = std::getenv("TRT_GROUP_FORCE_RCCL");  // test switch: a group of one device takes the RCCL route too
     g->use_rccl = distinct && (n_devices > 1 || (force && std::atoi(force) != 0));
-    for (int k = 0; k < n_devices; ++k) {
-        trt_handle* h = nullptr;
-        if (int e = trt_create(scene, devices[k], &h)) return e;  // message already set (TRT_ENODEV for an ordinal the node does not have)
-        g->handles.push_back(h);
-        g->devices.push_back(devices[k]);
+    {   // the host half of trt_create once (checks, collapses: seconds for 10 M triangles), the device half per member, side by side
+        SceneImage im;
+        if (int e = buildSceneImage(scene, im)) return e;
+        std::vector<trt_handle*> hs(n_devices, nullptr);
+        std::vector<int> rc(n_devices, TRT_OK);
+        std::vector<std::string> msg(n_devices);
+        std::vector<std::thread> th;
+        for (int k = 0; k < n_devices; ++k)
+            th.emplace_back([&, k] {
+                rc[k] = createOnDevice(im, devices[k], &hs[k]);
+                if (rc[k] != TRT_OK) msg[k] = trt_last_error();  // the message lives in this thread
+            });
+        for (std::thread& t : th) t.join();
+        for (int k = 0; k < n_devices; ++k) {
+            if (hs[k]) { g->handles.push_back(hs[k]); g->devices.push_back(devices[k]); }  // (owned by the group from here: freed with it on failure)
+        }
+        for (int k = 0; k < n_devices; ++k)
+            if (rc[k] != TRT_OK) return fail(rc[k], msg[k]);  // TRT_ENODEV for an ordinal the node does not have
     }
     g->stripe.resize(n_devices);
     g->streams.assign(n_devices, nullptr);

@@ -12,9 +12,11 @@
 // a 24-bit and an 8-bit significand), which is the premise of trt_oct.h's no-false-negative argument.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <memory>
 #include <vector>
 
 #include "trt_oct.h"
@@ -30,58 +32,63 @@ struct OctTree {
     const char* why = "";
 };
 
-inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t n_tris, const TriIsect* tri_isect)
+// `threads`: host threads to use (trt_wide.h, par); the tree does not depend on it.
+inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t n_tris, const TriIsect* tri_isect, unsigned threads = 1)
 {
     using namespace wide_detail;
     constexpr int W = 8;
     OctTree t;
     if (n_nodes2 == 0) { t.why = "no nodes"; return t; }
     // ---- premises: finite boxes with lo <= hi below 2^40, nested, leaves of <= 3 triangles
-    for (uint32_t n = 0; n < n_nodes2; ++n) {
-        Entry ch[2];
-        children(nodes2[n], ch);
-        for (int k = 0; k < 2; ++k) {
-            for (int a = 0; a < 3; ++a) {
-                const float lo = ch[k].b.lo[a], hi = ch[k].b.hi[a];
-                if (!(std::isfinite(lo) && std::isfinite(hi) && lo <= hi)) { t.why = "a box is not finite or has lo > hi"; return t; }
-                if (!(std::fabs(lo) < 1.0995116e12f && std::fabs(hi) < 1.0995116e12f)) { t.why = "coordinates of 2^40 or more"; return t; }
-            }
-            if (ch[k].ref & TRT_LEAF_BIT) {
-                if (TRT_LEAF_COUNT(ch[k].ref) > TRT_OCT_MAX_LEAF_TRIS) { t.why = "a leaf of more than 3 triangles"; return t; }
-                continue;
-            }
-            Entry g[2];
-            children(nodes2[ch[k].ref], g);
-            if (!contains(ch[k].b, g[0].b) || !contains(ch[k].b, g[1].b)) { t.why = "boxes are not nested"; return t; }
-        }
-    }
-    // ---- dynamic programme (trt_wide.h collapseBvh, eight children)
-    std::vector<double> area(n_nodes2, 0.0);
-    std::vector<uint32_t> order;
-    order.reserve(n_nodes2);
     {
-        std::vector<uint32_t> st{0u};
-        while (!st.empty()) {
-            const uint32_t n = st.back(); st.pop_back();
-            order.push_back(n);
-            Entry c[2];
-            children(nodes2[n], c);
-            for (int k = 0; k < 2; ++k)
-                if (!(c[k].ref & TRT_LEAF_BIT)) { area[c[k].ref] = halfAreaD(c[k].b); st.push_back(c[k].ref); }
-        }
-        Entry c[2];
-        children(nodes2[0], c);
-        Box rb;
-        for (int a = 0; a < 3; ++a) { rb.lo[a] = std::fmin(c[0].b.lo[a], c[1].b.lo[a]); rb.hi[a] = std::fmax(c[0].b.hi[a], c[1].b.hi[a]); }
-        area[0] = halfAreaD(rb);
+        struct Bad { uint32_t node; const char* why; };
+        const unsigned T = threads ? threads : 1;
+        std::vector<Bad> bad(T, Bad{0xFFFFFFFFu, ""});  // per chunk: the first node that fails (the lowest index decides the message)
+        std::atomic<unsigned> chunk{0};
+        par::forRange(n_nodes2, T, 65536, [&](size_t n0, size_t n1) {
+            Bad& mine = bad[chunk.fetch_add(1) % T];
+            for (size_t n = n0; n < n1 && mine.node == 0xFFFFFFFFu; ++n) {
+                Entry ch[2];
+                children(nodes2[n], ch);
+                const char* why = nullptr;
+                for (int k = 0; k < 2 && !why; ++k) {
+                    for (int a = 0; a < 3 && !why; ++a) {
+                        const float lo = ch[k].b.lo[a], hi = ch[k].b.hi[a];
+                        if (!(std::isfinite(lo) && std::isfinite(hi) && lo <= hi)) why = "a box is not finite or has lo > hi";
+                        else if (!(std::fabs(lo) < 1.0995116e12f && std::fabs(hi) < 1.0995116e12f)) why = "coordinates of 2^40 or more";
+                    }
+                    if (why) break;
+                    if (ch[k].ref & TRT_LEAF_BIT) {
+                        if (TRT_LEAF_COUNT(ch[k].ref) > TRT_OCT_MAX_LEAF_TRIS) why = "a leaf of more than 3 triangles";
+                        continue;
+                    }
+                    if (ch[k].ref >= n_nodes2) { why = "a child index out of range"; break; }  // (a node no path reaches: validateBvh does not see it)
+                    Entry g[2];
+                    children(nodes2[ch[k].ref], g);
+                    if (!contains(ch[k].b, g[0].b) || !contains(ch[k].b, g[1].b)) why = "boxes are not nested";
+                }
+                if (why) mine = Bad{(uint32_t)n, why};
+            }
+        });
+        const Bad* first = nullptr;
+        for (const Bad& x : bad)
+            if (x.node != 0xFFFFFFFFu && (!first || x.node < first->node)) first = &x;
+        if (first) { t.why = first->why; return t; }
     }
-    std::vector<double> rootc(n_nodes2, 0.0);
-    std::vector<double> best((size_t)n_nodes2 * (W - 1), 0.0);  // best[n * 7 + (k - 1)], k = 1..7: n's subtree as <= k children of a wide node
-    std::vector<uint8_t> split_root(n_nodes2, 1);
-    std::vector<uint8_t> split_k((size_t)n_nodes2 * (W - 1), 0);  // 0: n stays one child; else i of the (i, k - i) split
+    // ---- dynamic programme (trt_wide.h collapseBvh, eight children); tables uninitialised, first touched by the task that owns them
+    std::unique_ptr<double[]> area(new double[n_nodes2]);
+    std::unique_ptr<double[]> rootc(new double[n_nodes2]);
+    std::unique_ptr<double[]> best(new double[(size_t)n_nodes2 * (W - 1)]);  // best[n * 7 + (k - 1)], k = 1..7: n's subtree as <= k children of a wide node
+    std::unique_ptr<uint8_t[]> split_root(new uint8_t[n_nodes2]);
+    std::unique_ptr<uint8_t[]> split_k(new uint8_t[(size_t)n_nodes2 * (W - 1)]);  // 0: n stays one child; else i of the (i, k - i) split
     auto bestOf = [&](uint32_t ref, int k) -> double { return (ref & TRT_LEAF_BIT) ? 0.0 : best[(size_t)ref * (W - 1) + (k - 1)]; };
-    for (size_t idx = order.size(); idx-- > 0;) {
-        const uint32_t n = order[idx];
+    auto visitDown = [&](uint32_t n) {
+        Entry c[2];
+        children(nodes2[n], c);
+        for (int k = 0; k < 2; ++k)
+            if (!(c[k].ref & TRT_LEAF_BIT)) area[c[k].ref] = halfAreaD(c[k].b);
+    };
+    auto solve = [&](uint32_t n) {
         const uint32_t l = nodes2[n].child0, r = nodes2[n].child1;
         double br = 1.0e300; int bi = 1;
         for (int i = 1; i <= W - 1; ++i) { const double c = bestOf(l, i) + bestOf(r, W - i); if (c < br) { br = c; bi = i; } }
@@ -93,18 +100,42 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
             best[(size_t)n * (W - 1) + (k - 1)] = b;
             split_k[(size_t)n * (W - 1) + (k - 1)] = (uint8_t)s;
         }
+    };
+    {
+        Entry c[2];
+        children(nodes2[0], c);
+        Box rb;
+        for (int a = 0; a < 3; ++a) { rb.lo[a] = std::fmin(c[0].b.lo[a], c[1].b.lo[a]); rb.hi[a] = std::fmax(c[0].b.hi[a], c[1].b.hi[a]); }
+        area[0] = halfAreaD(rb);
     }
-    // ---- emit, parents before children, a node's inner children next to each other
-    struct Job { uint32_t bvh2, oct, level; };
-    std::vector<Job> jobs;
-    t.nodes.reserve(n_nodes2 / 4 + 1);
-    t.tri_trav.reserve(n_tris);
-    t.nodes.emplace_back();
-    jobs.push_back({0u, 0u, 1u});
-    size_t head = 0;
-    while (head < jobs.size()) {  // FIFO: breadth first (the upper levels end up together at the front of the array)
-        const Job j = jobs[head++];
-        t.levels = std::max(t.levels, j.level);
+    {
+        const TreeCut cut = cutTree(nodes2, threads);
+        for (uint32_t n : cut.top) visitDown(n);
+        par::forTasks(cut.roots.size(), threads, [&](size_t ti) {
+            std::vector<uint32_t> order, st{cut.roots[ti]};
+            while (!st.empty()) {
+                const uint32_t n = st.back(); st.pop_back();
+                order.push_back(n);
+                visitDown(n);
+                if (!(nodes2[n].child0 & TRT_LEAF_BIT)) st.push_back(nodes2[n].child0);
+                if (!(nodes2[n].child1 & TRT_LEAF_BIT)) st.push_back(nodes2[n].child1);
+            }
+            for (size_t idx = order.size(); idx-- > 0;) solve(order[idx]);
+        });
+        for (size_t idx = cut.top.size(); idx-- > 0;) solve(cut.top[idx]);
+    }
+    // ---- emit level by level (breadth first: the upper levels end up together at the front of the array), parents before children, a
+    // node's inner children next to each other in slot order, its leaf triangles likewise.  Per level: every node is laid out on its own
+    // (phase A), a prefix sum over the level hands out the child and triangle indices, and the nodes are written (phase B).
+    struct Job { uint32_t bvh2, oct; };
+    struct Draft {
+        OctNode on;          // complete but for child_base / tri_base
+        uint32_t ref[W];     // per slot: the BVH2 reference of the child in it (TRT_WIDE_EMPTY: none)
+        uint32_t n_inner, n_tri;
+        uint32_t child_base, tri_base;
+        bool ok;
+    };
+    auto draft = [&](const Job& j, Draft& d) {
         Entry e[W];
         int n = 0;
         {
@@ -162,6 +193,7 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
         // quantisation
         uint32_t ebits[3];
         uint32_t qlo[3][W], qhi[3][W];
+        d.ok = true;
         for (int a = 0; a < 3; ++a) {
             const double p = lo[a], ext = hi[a] - lo[a];
             int eb = 1;
@@ -171,7 +203,7 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
                 eb = std::max(ex + 127, 1);
             }
             for (;; ++eb) {
-                if (eb > 254) { t.nodes.clear(); t.tri_trav.clear(); t.why = "extent not representable"; return t; }
+                if (eb > 254) { d.ok = false; return; }
                 const double s = std::ldexp(1.0, eb - 127);
                 bool fits = true;
                 for (int sl = 0; sl < W && fits; ++sl) {
@@ -192,40 +224,83 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
             ebits[a] = (uint32_t)eb;
         }
         // children: inner ones get consecutive node indices in slot order, leaf triangles consecutive records in slot order
-        const uint32_t child_base = (uint32_t)t.nodes.size(), tri_base = (uint32_t)t.tri_trav.size();
-        uint32_t imask = 0u, tri_off = 0u;
+        uint32_t imask = 0u, tri_off = 0u, n_inner = 0u;
         uint8_t meta[W];
         for (int sl = 0; sl < W; ++sl) {
             meta[sl] = 0;
+            d.ref[sl] = TRT_WIDE_EMPTY;
             const int k = child_in[sl];
             if (k < 0) continue;
             const uint32_t ref = e[k].ref;
+            d.ref[sl] = ref;
             if (ref & TRT_LEAF_BIT) {
-                const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
+                const uint32_t count = TRT_LEAF_COUNT(ref);
                 meta[sl] = (uint8_t)((((1u << count) - 1u) << 5) | tri_off);
-                for (uint32_t i = 0; i < count; ++i) {
-                    TriIsect T = tri_isect[first + i];
-                    T.c.w = u2f((first + i) | (i << 27) | (count << 29));
-                    t.tri_trav.push_back(T);
-                }
                 tri_off += count;
             } else {
                 imask |= 1u << sl;
                 meta[sl] = (uint8_t)(0x20u | (24u + (uint32_t)sl));
-                const uint32_t idx = (uint32_t)t.nodes.size();
-                t.nodes.emplace_back();
-                jobs.push_back({ref, idx, j.level + 1});
+                ++n_inner;
             }
         }
+        d.n_inner = n_inner;
+        d.n_tri = tri_off;
         auto pack4 = [](const uint32_t* v) { return v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24); };
         auto packm = [](const uint8_t* v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); };
-        OctNode on;
-        on.q[0] = mk4((float)lo[0], (float)lo[1], (float)lo[2], u2f(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (imask << 24)));
-        on.q[1] = mk4(u2f(child_base), u2f(tri_base), u2f(packm(meta)), u2f(packm(meta + 4)));
-        on.q[2] = mk4(u2f(pack4(qlo[0])), u2f(pack4(qlo[0] + 4)), u2f(pack4(qlo[1])), u2f(pack4(qlo[1] + 4)));
-        on.q[3] = mk4(u2f(pack4(qlo[2])), u2f(pack4(qlo[2] + 4)), u2f(pack4(qhi[0])), u2f(pack4(qhi[0] + 4)));
-        on.q[4] = mk4(u2f(pack4(qhi[1])), u2f(pack4(qhi[1] + 4)), u2f(pack4(qhi[2])), u2f(pack4(qhi[2] + 4)));
-        t.nodes[j.oct] = on;
+        d.on.q[0] = mk4((float)lo[0], (float)lo[1], (float)lo[2], u2f(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (imask << 24)));
+        d.on.q[1] = mk4(0.f, 0.f, u2f(packm(meta)), u2f(packm(meta + 4)));
+        d.on.q[2] = mk4(u2f(pack4(qlo[0])), u2f(pack4(qlo[0] + 4)), u2f(pack4(qlo[1])), u2f(pack4(qlo[1] + 4)));
+        d.on.q[3] = mk4(u2f(pack4(qlo[2])), u2f(pack4(qlo[2] + 4)), u2f(pack4(qhi[0])), u2f(pack4(qhi[0] + 4)));
+        d.on.q[4] = mk4(u2f(pack4(qhi[1])), u2f(pack4(qhi[1] + 4)), u2f(pack4(qhi[2])), u2f(pack4(qhi[2] + 4)));
+    };
+    std::vector<Job> cur{{0u, 0u}}, next;
+    std::vector<Draft> drafts;
+    t.nodes.reserve(n_nodes2 / 4 + 1);
+    t.tri_trav.reserve(n_tris);
+    t.nodes.emplace_back();
+    while (!cur.empty()) {
+        ++t.levels;
+        drafts.resize(cur.size());
+        par::forRange(cur.size(), threads, 256, [&](size_t j0, size_t j1) {
+            for (size_t j = j0; j < j1; ++j) draft(cur[j], drafts[j]);
+        });
+        size_t n_nodes = t.nodes.size(), n_tt = t.tri_trav.size();
+        for (Draft& d : drafts) {
+            if (!d.ok) { t.nodes.clear(); t.tri_trav.clear(); t.levels = 0; t.why = "extent not representable"; return t; }
+            d.child_base = (uint32_t)n_nodes;
+            d.tri_base = (uint32_t)n_tt;
+            n_nodes += d.n_inner;
+            n_tt += d.n_tri;
+        }
+        const size_t first_child = t.nodes.size();
+        t.nodes.resize(n_nodes);
+        t.tri_trav.resize(n_tt);
+        next.resize(n_nodes - first_child);
+        par::forRange(cur.size(), threads, 256, [&](size_t j0, size_t j1) {
+            for (size_t j = j0; j < j1; ++j) {
+                Draft& d = drafts[j];
+                d.on.q[1].x = u2f(d.child_base);
+                d.on.q[1].y = u2f(d.tri_base);
+                t.nodes[cur[j].oct] = d.on;
+                uint32_t ci = d.child_base, ti = d.tri_base;
+                for (int sl = 0; sl < W; ++sl) {
+                    const uint32_t ref = d.ref[sl];
+                    if (ref == TRT_WIDE_EMPTY) continue;
+                    if (ref & TRT_LEAF_BIT) {
+                        const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
+                        for (uint32_t i = 0; i < count; ++i) {
+                            TriIsect T = tri_isect[first + i];
+                            T.c.w = u2f((first + i) | (i << 27) | (count << 29));
+                            t.tri_trav[ti++] = T;
+                        }
+                    } else {
+                        next[ci - first_child] = Job{ref, ci};
+                        ++ci;
+                    }
+                }
+            }
+        });
+        cur.swap(next);
     }
     if (t.tri_trav.empty()) t.tri_trav.push_back(TriIsect{mk4(0, 0, 0, 0), mk4(0, 0, 0, 0), mk4(0, 0, 0, 0)});
     t.ok = true;
@@ -237,10 +312,12 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
 inline std::vector<LightBox> lightBoxesOf(const std::vector<f4>& lb, const int32_t* tri_mat, uint32_t n_tris, const trt_light* lights, uint32_t n_lights)
 {
     std::vector<LightBox> out(n_lights, LightBox{{3.0e38f, 3.0e38f, 3.0e38f}, {-3.0e38f, -3.0e38f, -3.0e38f}});
-    for (uint32_t l = 0; l < n_lights; ++l) {
-        LightBox& B = out[l];
-        for (uint32_t i = 0; i < n_tris; ++i) {
-            if (tri_mat[i] != lights[l].mat) continue;
+    if (n_lights == 0) return out;
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        const int32_t m = tri_mat[i];
+        for (uint32_t l = 0; l < n_lights; ++l) {
+            if (m != lights[l].mat) continue;
+            LightBox& B = out[l];
             const f4 a = lb[2 * (size_t)i], b = lb[2 * (size_t)i + 1];
             B.lo[0] = std::fmin(B.lo[0], a.x); B.lo[1] = std::fmin(B.lo[1], a.y); B.lo[2] = std::fmin(B.lo[2], a.z);
             B.hi[0] = std::fmax(B.hi[0], a.w); B.hi[1] = std::fmax(B.hi[1], b.x); B.hi[2] = std::fmax(B.hi[2], b.y);

@@ -94,27 +94,81 @@ struct Builder {
         return true;
     }
 
-    // 32-bin SAH on the centroid bounds; O(n) per node.
-    bool binnedSplit(size_t lo, size_t hi, size_t& mid_out)
+    // 32-bin SAH on the centroid bounds; O(n) per node: one pass for the centroid bounds, ONE for the bins of all three axes, one
+    // for the partition; the boxes of the two sides fall out of the bins (unions of the same triangle boxes).  A big node (the top of
+    // a 10 M-triangle tree: the root alone is 10 M gathers per pass) splits every pass into chunks run as OpenMP tasks; the
+    // partition is then a stable one through a scratch array (chunk counts, prefix, scatter), so the result does not depend on the
+    // number of chunks or threads.
+    static constexpr int NB = 32;
+    static constexpr size_t CHUNK = 131072;  // a node of >= 2 chunks is split across tasks
+    struct Bins {
+        Box bb[3][NB];
+        uint32_t cnt[3][NB];
+        Bins() { std::memset(cnt, 0, sizeof(cnt)); }
+        void merge(const Bins& o)
+        {
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < NB; ++b) { bb[a][b].grow(o.bb[a][b]); cnt[a][b] += o.cnt[a][b]; }
+        }
+    };
+    static int binOf(float c, float base, float scale)
     {
-        constexpr int NB = 32;
+        int b = (int)((c - base) * scale);
+        return b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+    }
+    template <class F>
+    static void chunked(size_t lo, size_t hi, F f)  // f(chunk index, begin, end); chunks of CHUNK elements as tasks
+    {
+        const size_t n = hi - lo, nc = (n + CHUNK - 1) / CHUNK;
+        if (nc <= 1) { f((size_t)0, lo, hi); return; }
+        for (size_t c = 0; c < nc; ++c) {
+            const size_t b = lo + c * CHUNK, e = std::min(hi, b + CHUNK);
+#pragma omp task firstprivate(c, b, e) shared(f)
+            f(c, b, e);
+        }
+#pragma omp taskwait
+    }
+    bool binnedSplit(size_t lo, size_t hi, size_t& mid_out, Box& b0, Box& b1)
+    {
+        const size_t n = hi - lo, nc = (n + CHUNK - 1) / CHUNK;
         Box cb;
-        for (size_t i = lo; i < hi; ++i) cb.grow(prims[idx[i]].c);
+        {
+            std::vector<Box> part(nc);
+            chunked(lo, hi, [&](size_t c, size_t b, size_t e) {
+                Box x;
+                for (size_t i = b; i < e; ++i) x.grow(prims[idx[i]].c);
+                part[c] = x;
+            });
+            for (const Box& x : part) cb.grow(x);
+        }
+        float scale[3];
+        for (int axis = 0; axis < 3; ++axis) {
+            const float ext = cb.hi[axis] - cb.lo[axis];
+            scale[axis] = ext > 0.f ? (float)NB / ext : 0.f;
+        }
+        Bins bins;
+        {
+            std::vector<Bins> part(nc);
+            chunked(lo, hi, [&](size_t c, size_t b, size_t e) {
+                Bins& x = part[c];
+                for (size_t i = b; i < e; ++i) {
+                    const Prim& p = prims[idx[i]];
+                    for (int axis = 0; axis < 3; ++axis) {
+                        if (!(scale[axis] > 0.f)) continue;
+                        const int k = binOf(p.c[axis], cb.lo[axis], scale[axis]);
+                        x.bb[axis][k].grow(p.box);
+                        x.cnt[axis][k]++;
+                    }
+                }
+            });
+            for (const Bins& x : part) bins.merge(x);
+        }
         float best = std::numeric_limits<float>::max();
         int best_axis = -1, best_bin = 0;
         for (int axis = 0; axis < 3; ++axis) {
-            const float ext = cb.hi[axis] - cb.lo[axis];
-            if (!(ext > 0.f)) continue;
-            const float scale = (float)NB / ext;
-            Box bb[NB];
-            uint32_t cnt[NB] = {0};
-            for (size_t i = lo; i < hi; ++i) {
-                const Prim& p = prims[idx[i]];
-                int b = (int)((p.c[axis] - cb.lo[axis]) * scale);
-                b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
-                bb[b].grow(p.box);
-                cnt[b]++;
-            }
+            if (!(scale[axis] > 0.f)) continue;
+            const Box* bb = bins.bb[axis];
+            const uint32_t* cnt = bins.cnt[axis];
             float ra[NB];
             uint32_t rc[NB];
             Box acc;
@@ -136,46 +190,154 @@ struct Builder {
             }
         }
         if (best_axis < 0) return false;
-        const float ext = cb.hi[best_axis] - cb.lo[best_axis];
-        const float scale = (float)NB / ext;
-        const float base = cb.lo[best_axis];
-        auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](uint32_t a) {
-            int b = (int)((prims[a].c[best_axis] - base) * scale);
-            b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
-            return b < best_bin;
-        });
-        mid_out = (size_t)(it - idx.begin());
-        return mid_out > lo && mid_out < hi;
+        const float sc = scale[best_axis], base = cb.lo[best_axis];
+        auto left = [&](uint32_t a) { return binOf(prims[a].c[best_axis], base, sc) < best_bin; };
+        if (nc <= 1) {
+            auto it = std::partition(idx.begin() + lo, idx.begin() + hi, left);
+            mid_out = (size_t)(it - idx.begin());
+        } else {
+            std::vector<size_t> nleft(nc, 0);
+            chunked(lo, hi, [&](size_t c, size_t b, size_t e) {
+                size_t k = 0;
+                for (size_t i = b; i < e; ++i) k += left(idx[i]) ? 1 : 0;
+                nleft[c] = k;
+            });
+            std::vector<size_t> lpos(nc), rpos(nc);
+            size_t total_left = 0;
+            for (size_t c = 0; c < nc; ++c) { lpos[c] = total_left; total_left += nleft[c]; }
+            size_t r = total_left;
+            for (size_t c = 0; c < nc; ++c) { rpos[c] = r; r += std::min(hi, lo + (c + 1) * CHUNK) - (lo + c * CHUNK) - nleft[c]; }
+            std::vector<uint32_t> tmp(n);
+            chunked(lo, hi, [&](size_t c, size_t b, size_t e) {
+                size_t l = lpos[c], q = rpos[c];
+                for (size_t i = b; i < e; ++i) {
+                    const uint32_t a = idx[i];
+                    if (left(a)) tmp[l++] = a; else tmp[q++] = a;
+                }
+            });
+            chunked(lo, hi, [&](size_t, size_t b, size_t e) { std::memcpy(&idx[b], &tmp[b - lo], (e - b) * sizeof(uint32_t)); });
+            mid_out = lo + total_left;
+        }
+        if (!(mid_out > lo && mid_out < hi)) return false;
+        b0 = Box();
+        b1 = Box();
+        for (int b = 0; b < NB; ++b) (b < best_bin ? b0 : b1).grow(bins.bb[best_axis][b]);
+        return true;
     }
 
     // Chooses the split of idx[lo,hi) (reordering that range) and returns its position.
-    size_t split(size_t lo, size_t hi, uint32_t depth)
+    // `have_boxes`: b0 / b1 are the bounds of the two sides already (the binned split knows them).
+    size_t split(size_t lo, size_t hi, uint32_t depth, bool& have_boxes, Box& b0, Box& b1)
     {
         const size_t n = hi - lo;
         size_t mid = lo + n / 2;
         const bool use_sweep = kind == BVH_SWEEP_SAH || (kind == BVH_AUTO && n <= 65536);
         bool ok = false;
+        have_boxes = false;
         if (depth < 56) {
             if (use_sweep) { int axis; ok = sweepSplit(lo, hi, axis, mid); }
-            else ok = binnedSplit(lo, hi, mid);
+            else have_boxes = ok = binnedSplit(lo, hi, mid, b0, b1);
         }
         if (!ok) mid = lo + n / 2;  // degenerate input (coincident centroids) or a runaway depth: median by index
         return mid;
     }
 
+    // ---- exact SAH below SWEEP_MAX triangles, the three centroid orders kept instead of re-made ----
+    // sweepSplit() sorts a node's range three to four times; over the 16 levels below 65 536 triangles that was 60 % of the
+    // build of a 2 M-triangle scene.  Here the subtree's range is sorted ONCE per axis (same comparator: a total order), a node
+    // is evaluated by scanning the three orders — the same boxes grown in the same sequence, so the same costs and the same
+    // choice as sweepSplit() —, and the two orders of the axes not chosen are split by a stable partition, which leaves each side
+    // in exactly the order a fresh sort would give it.  A leaf takes its triangles in the order of its parent's split axis, which
+    // is where sweepSplit() leaves them.  Same tree, same triangle order, O(n) per node.
+    struct Sorted {
+        size_t base = 0;              // order[a][i - base] for position i of idx
+        std::vector<uint32_t> order[3];
+        std::vector<uint32_t> tmp;
+    };
+    uint8_t* side = nullptr;          // per triangle: which side of the current split (shared by all tasks: disjoint triangles)
+
+    uint32_t buildSorted(Sorted& S, size_t lo, size_t hi, uint32_t depth, int parent_axis, std::vector<trt_bvh_node>& out, uint32_t& deepest)
+    {
+        const size_t n = hi - lo;
+        auto at = [&](int a, size_t i) -> uint32_t& { return S.order[a][i - S.base]; };
+        if (n <= (size_t)leaf_num || depth >= 56) {
+            if (parent_axis >= 0)
+                for (size_t i = lo; i < hi; ++i) idx[i] = at(parent_axis, i);
+            // (a runaway depth: build() goes on with medians by index and never sorts again)
+            return build(lo, hi, depth, out, deepest, false);
+        }
+        float best = std::numeric_limits<float>::max();
+        int best_axis = -1;
+        size_t best_mid = lo + n / 2;
+        if (scratch_area.size() < n) scratch_area.resize(n);
+        for (int axis = 0; axis < 3; ++axis) {
+            Box acc;
+            for (size_t i = n; i-- > 1;) {
+                acc.grow(prims[at(axis, lo + i)].box);
+                scratch_area[i] = acc.halfArea();
+            }
+            acc = Box();
+            for (size_t i = 1; i < n; ++i) {
+                acc.grow(prims[at(axis, lo + i - 1)].box);
+                const float cost = acc.halfArea() * (float)i + scratch_area[i] * (float)(n - i);
+                if (cost < best) { best = cost; best_axis = axis; best_mid = lo + i; }
+            }
+        }
+        if (best_axis < 0) { best_axis = 0; best_mid = lo + n / 2; }
+        const size_t mid = best_mid;
+        Box b0, b1;
+        for (size_t i = lo; i < mid; ++i) { const uint32_t a = at(best_axis, i); side[a] = 0; b0.grow(prims[a].box); }
+        for (size_t i = mid; i < hi; ++i) { const uint32_t a = at(best_axis, i); side[a] = 1; b1.grow(prims[a].box); }
+        for (int axis = 0; axis < 3; ++axis) {
+            if (axis == best_axis) continue;
+            size_t l = lo, r = 0;
+            if (S.tmp.size() < n) S.tmp.resize(n);
+            for (size_t i = lo; i < hi; ++i) {
+                const uint32_t a = at(axis, i);
+                if (side[a]) S.tmp[r++] = a; else at(axis, l++) = a;  // (l <= i: nothing unread is overwritten)
+            }
+            for (size_t k = 0; k < r; ++k) at(axis, l + k) = S.tmp[k];
+        }
+        const uint32_t me = (uint32_t)out.size();
+        out.emplace_back();
+        const uint32_t c0 = buildSorted(S, lo, mid, depth + 1, best_axis, out, deepest);
+        const uint32_t c1 = buildSorted(S, mid, hi, depth + 1, best_axis, out, deepest);
+        trt_bvh_node& nd = out[me];
+        storeBox(nd.lo0, nd.hi0, b0);
+        storeBox(nd.lo1, nd.hi1, b1);
+        nd.child0 = c0;
+        nd.child1 = c1;
+        nd.reserved[0] = nd.reserved[1] = 0;
+        return me;
+    }
+
     // Builds the subtree over idx[lo,hi) into `out` (appending, parents before children) and returns its
     // child reference; inner references are absolute indices into `out`.
-    uint32_t build(size_t lo, size_t hi, uint32_t depth, std::vector<trt_bvh_node>& out, uint32_t& deepest)
+    uint32_t build(size_t lo, size_t hi, uint32_t depth, std::vector<trt_bvh_node>& out, uint32_t& deepest, bool sorted_ok = true)
     {
         const size_t n = hi - lo;
         if (n <= (size_t)leaf_num) {
             if (depth > deepest) deepest = depth;
             return TRT_MAKE_LEAF(lo, n);
         }
-        const size_t mid = split(lo, hi, depth);
+        if (sorted_ok && side && depth < 56 && n < PARALLEL_MIN && (kind == BVH_SWEEP_SAH || (kind == BVH_AUTO && n <= 65536))) {
+            Sorted S;
+            S.base = lo;
+            for (int axis = 0; axis < 3; ++axis) {
+                S.order[axis].assign(idx.begin() + (long)lo, idx.begin() + (long)hi);
+                std::sort(S.order[axis].begin(), S.order[axis].end(), [&](uint32_t a, uint32_t b) {
+                    const float ca = prims[a].c[axis], cb = prims[b].c[axis];
+                    return ca < cb || (ca == cb && a < b);
+                });
+            }
+            return buildSorted(S, lo, hi, depth, -1, out, deepest);
+        }
+        bool have_boxes = false;
+        Box b0, b1;
+        const size_t mid = split(lo, hi, depth, have_boxes, b0, b1);
         const uint32_t me = (uint32_t)out.size();
         out.emplace_back();
-        const Box b0 = bounds(lo, mid), b1 = bounds(mid, hi);
+        if (!have_boxes) { b0 = bounds(lo, mid); b1 = bounds(mid, hi); }
         uint32_t c0, c1;
         if (n >= PARALLEL_MIN) {
             // big subtrees: the two halves are independent -> OpenMP tasks, each into its own node vector
@@ -185,12 +347,14 @@ struct Builder {
 #pragma omp task shared(left, dl, rl) if (n >= PARALLEL_MIN)
             {
                 Builder sub(prims, idx, leaf_num, kind);
-                rl = sub.build(lo, mid, depth + 1, left, dl);
+                sub.side = side;
+                rl = sub.build(lo, mid, depth + 1, left, dl, sorted_ok);
             }
 #pragma omp task shared(right, dr, rr) if (n >= PARALLEL_MIN)
             {
                 Builder sub(prims, idx, leaf_num, kind);
-                rr = sub.build(mid, hi, depth + 1, right, dr);
+                sub.side = side;
+                rr = sub.build(mid, hi, depth + 1, right, dr, sorted_ok);
             }
 #pragma omp taskwait
             auto splice = [&](std::vector<trt_bvh_node>& sub, uint32_t ref) -> uint32_t {
@@ -206,8 +370,8 @@ struct Builder {
             c1 = splice(right, rr);
             deepest = std::max(deepest, std::max(dl, dr));
         } else {
-            c0 = build(lo, mid, depth + 1, out, deepest);
-            c1 = build(mid, hi, depth + 1, out, deepest);
+            c0 = build(lo, mid, depth + 1, out, deepest, sorted_ok);
+            c1 = build(mid, hi, depth + 1, out, deepest, sorted_ok);
         }
         trt_bvh_node& nd = out[me];
         storeBox(nd.lo0, nd.hi0, b0);
@@ -228,6 +392,7 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
     if (triangles.size() > TRT_MAX_TRIS) throw std::runtime_error("buildBVH: too many triangles");
     const size_t n = triangles.size();
     std::vector<Prim> prims(n);
+#pragma omp parallel for schedule(static) if (n >= 100000)
     for (size_t i = 0; i < n; ++i) {
         const Triangle& t = triangles[i];
         prims[i].box.grow(t.v[0]);
@@ -239,6 +404,8 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
     std::iota(idx.begin(), idx.end(), 0u);
 
     Builder b(prims, idx, leaf_num, builder);
+    std::vector<uint8_t> side(n, 0);
+    b.side = side.data();
     FlatBVH out;
     if (n <= (size_t)leaf_num) {
         // A scene that fits one leaf still gets a root node: child0 = all
@@ -264,9 +431,9 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
     out.depth = deepest;
 
     // reorder the triangles into leaf order (the reference's in-place sorts)
-    std::vector<Triangle> sorted;
-    sorted.reserve(n);
-    for (size_t i = 0; i < n; ++i) sorted.push_back(std::move(triangles[idx[i]]));
+    std::vector<Triangle> sorted(n);
+#pragma omp parallel for schedule(static) if (n >= 100000)
+    for (size_t i = 0; i < n; ++i) sorted[i] = std::move(triangles[idx[i]]);  // idx is a permutation: every source moved once
     triangles.swap(sorted);
     return out;
 }
@@ -278,6 +445,8 @@ void FlatScene::build(const Scene& scene, const FlatBVH& bvh)
     tri_vn.resize(n * 9);
     tri_vt.resize(n * 6);
     tri_mat.resize(n);
+    int bad_material = 0;
+#pragma omp parallel for schedule(static) if (n >= 100000)
     for (size_t i = 0; i < n; ++i) {
         const Triangle& t = scene.triangles[i];
         for (int k = 0; k < 3; ++k) {
@@ -285,9 +454,13 @@ void FlatScene::build(const Scene& scene, const FlatBVH& bvh)
             tri_vn[i * 9 + k * 3 + 0] = t.vn[k].x; tri_vn[i * 9 + k * 3 + 1] = t.vn[k].y; tri_vn[i * 9 + k * 3 + 2] = t.vn[k].z;
             tri_vt[i * 6 + k * 2 + 0] = t.vt[k].x; tri_vt[i * 6 + k * 2 + 1] = t.vt[k].y;
         }
-        if (t.mtl_id < 0 || t.mtl_id >= (int)scene.materials.size()) throw std::runtime_error("flatten: triangle without material");
+        if (t.mtl_id < 0 || t.mtl_id >= (int)scene.materials.size()) {
+#pragma omp atomic write
+            bad_material = 1;  // (no exception out of a parallel loop)
+        }
         tri_mat[i] = t.mtl_id;
     }
+    if (bad_material) throw std::runtime_error("flatten: triangle without material");
     nodes = bvh.nodes;
 
     materials.resize(scene.materials.size());
