@@ -104,3 +104,45 @@ def test_trt_create_validates_the_bvh_before_touching_a_device():
             nodes[0].child0, nodes[0].child1 = f.nodes[0].child1, f.nodes[0].child0
         assert lib.trt_create(C.byref(g), 0, C.byref(h)) == 1
         assert needle in lib.trt_last_error(), (what, lib.trt_last_error())
+
+
+def test_validation_on_several_host_threads_finds_faults_deep_in_a_big_tree(monkeypatch):
+    """trt_create validates subtrees of a cut of the tree side by side (atomic marks): the same faults are found when they sit deep
+    below the cut of a 90 k-node tree, with 1 and with 8 host threads; the untouched tree passes validation (and then fails for
+    want of a device on a machine without one, or succeeds)."""
+    import numpy as np
+    import tinyraytracing_amd as T
+    from tinyraytracing_amd._abi import BvhNode, SceneFlat
+    lib = _abi.load_hip()
+    s = T.Scene.named("blob", 32, 18, n=150000)
+    f = s.flat.contents
+    g = SceneFlat()
+    C.memmove(C.byref(g), C.byref(f), C.sizeof(SceneFlat))
+    nodes = (BvhNode * f.n_nodes)()
+    g.nodes = nodes
+    LEAF = 0x80000000
+    inner = [n for n in range(f.n_nodes - 2000, f.n_nodes) if not (f.nodes[n].child0 & LEAF) and not (f.nodes[n].child1 & LEAF)]
+    leafy = [n for n in range(f.n_nodes - 2000, f.n_nodes) if (f.nodes[n].child0 & LEAF) and (f.nodes[n].child1 & LEAF)]
+    assert inner and leafy
+    h = C.c_void_p()
+    for threads in ("1", "8"):
+        monkeypatch.setenv("TRT_HOST_THREADS", threads)
+        for what, needle in (("index", b"out of range"), ("cycle", b"twice"), ("order", b"post-BVH order"), ("shared", b"two leaves"), ("none", None)):
+            C.memmove(nodes, f.nodes, C.sizeof(BvhNode) * f.n_nodes)
+            n = inner[len(inner) // 2]
+            if what == "index":
+                nodes[n].child1 = 0x7FFFFFF0
+            elif what == "cycle":
+                nodes[n].child0 = n - 1000
+            elif what == "order":
+                nodes[n].child0, nodes[n].child1 = f.nodes[n].child1, f.nodes[n].child0
+            elif what == "shared":
+                nodes[leafy[0]].child1 = f.nodes[leafy[-1]].child0
+            rc = lib.trt_create(C.byref(g), 0, C.byref(h))
+            if needle is None:
+                assert rc == 0 or b"HIP device" in lib.trt_last_error() or b"gfx950" in lib.trt_last_error(), lib.trt_last_error()
+                if rc == 0:
+                    lib.trt_destroy(h)
+            else:
+                assert rc == 1 and needle in lib.trt_last_error(), (threads, what, rc, lib.trt_last_error())
+    s.close()

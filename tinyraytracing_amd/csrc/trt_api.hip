@@ -159,71 +159,97 @@ int upload(trt_handle* h, const T* src, size_t count, const T** dst)
 // reference (bvh.cpp sorts the triangle array in place and recurses on its two halves),
 // which is what lets the between-leaves tie rule "r1 if r1 emissive else r2" (bvh.cpp:168-172)
 // be applied by triangle index in any visiting order.
-int validateBvh(const trt_scene* s, uint32_t* depth_out)
+int validateBvh(const trt_scene* s, uint32_t* depth_out, unsigned threads = 1)
 {
-    std::vector<uint8_t> seen(s->n_nodes, 0);
-    std::vector<std::pair<uint32_t, uint32_t>> stack;  // (node, depth of this inner node, 1-based)
-    stack.emplace_back(0u, 1u);
-    uint32_t max_depth = 0;
-    std::vector<uint8_t> tri_seen(s->n_tris, 0);
-    while (!stack.empty()) {
-        const auto [ni, dep] = stack.back();
-        stack.pop_back();
-        if (ni >= s->n_nodes) return fail(TRT_EINVAL, "bvh: child index out of range");
-        if (seen[ni]) return fail(TRT_EINVAL, "bvh: node reachable twice");
-        seen[ni] = 1;
-        if (dep > MAX_BVH_DEPTH) return fail(TRT_EINVAL, "bvh: deeper than 256 levels");
-        max_depth = std::max(max_depth, dep);
+    // One walk per subtree of a cut of the tree (the cut itself, a few hundred nodes, is walked here first), subtrees side by side on
+    // `threads` host threads: marks are atomic bytes, so a node or triangle that two walks reach is caught whichever gets there second.
+    const uint32_t nn = s->n_nodes;
+    std::unique_ptr<std::atomic<uint8_t>[]> seen(new std::atomic<uint8_t>[nn]);
+    std::unique_ptr<std::atomic<uint8_t>[]> tri_seen(new std::atomic<uint8_t>[std::max<uint32_t>(s->n_tris, 1u)]);
+    par::forRange(nn, threads, 1u << 20, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) seen[i].store(0, std::memory_order_relaxed); });
+    par::forRange(s->n_tris, threads, 1u << 20, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) tri_seen[i].store(0, std::memory_order_relaxed); });
+    // (min, max) triangle index under every inner node: index order of siblings, children before parents
+    std::unique_ptr<uint32_t[]> lo(new uint32_t[nn]), hi(new uint32_t[nn]);
+    std::unique_ptr<uint8_t[]> has(new uint8_t[nn]);
+    // what one node says about itself: its own checks, its inner children appended to `kids`; nullptr or the complaint
+    auto visit = [&](uint32_t ni, uint32_t dep, uint32_t* kids, int& n_kids) -> const char* {
+        n_kids = 0;
+        if (ni >= nn) return "bvh: child index out of range";
+        if (seen[ni].exchange(1, std::memory_order_relaxed)) return "bvh: node reachable twice";
+        if (dep > MAX_BVH_DEPTH) return "bvh: deeper than 256 levels";
         const uint32_t ch[2] = {s->nodes[ni].child0, s->nodes[ni].child1};
         for (uint32_t c : ch) {
             if (c & TRT_LEAF_BIT) {
                 const uint32_t first = TRT_LEAF_FIRST(c), count = TRT_LEAF_COUNT(c);
-                if ((uint64_t)first + count > s->n_tris) return fail(TRT_EINVAL, "bvh: leaf range out of bounds");
-                for (uint32_t i = first; i < first + count; ++i) {
-                    if (tri_seen[i]) return fail(TRT_EINVAL, "bvh: triangle in two leaves");
-                    tri_seen[i] = 1;
-                }
+                if ((uint64_t)first + count > s->n_tris) return "bvh: leaf range out of bounds";
+                for (uint32_t i = first; i < first + count; ++i)
+                    if (tri_seen[i].exchange(1, std::memory_order_relaxed)) return "bvh: triangle in two leaves";
             } else {
-                stack.emplace_back(c, dep + 1);
+                kids[n_kids++] = c;
             }
         }
+        return nullptr;
+    };
+    auto order_rule = [&](uint32_t n) -> const char* {  // children already done
+        uint32_t clo[2], chi[2];
+        bool chas[2];
+        const uint32_t ch[2] = {s->nodes[n].child0, s->nodes[n].child1};
+        for (int c = 0; c < 2; ++c) {
+            if (ch[c] & TRT_LEAF_BIT) {
+                const uint32_t first = TRT_LEAF_FIRST(ch[c]), count = TRT_LEAF_COUNT(ch[c]);
+                chas[c] = count != 0;
+                clo[c] = first;
+                chi[c] = first + count - (count ? 1u : 0u);
+            } else {
+                chas[c] = has[ch[c]] != 0;
+                clo[c] = lo[ch[c]];
+                chi[c] = hi[ch[c]];
+            }
+        }
+        if (chas[0] && chas[1] && !(chi[0] < clo[1])) return "bvh: triangles under child0 must precede those under child1 (post-BVH order)";
+        has[n] = chas[0] || chas[1];
+        lo[n] = std::min(chas[0] ? clo[0] : 0xFFFFFFFFu, chas[1] ? clo[1] : 0xFFFFFFFFu);
+        hi[n] = std::max(chas[0] ? chi[0] : 0u, chas[1] ? chi[1] : 0u);
+        return nullptr;
+    };
+    struct Ref { uint32_t node, depth; };
+    std::vector<Ref> top{{0u, 1u}};  // the cut: breadth first, parents before children
+    size_t head = 0;
+    uint32_t max_depth = 0;
+    const size_t want = threads > 1 ? (size_t)threads * 16 : 1;
+    while (threads > 1 && head < top.size() && top.size() - head < want) {
+        const Ref r = top[head++];
+        uint32_t kids[2];
+        int nk;
+        if (const char* why = visit(r.node, r.depth, kids, nk)) return fail(TRT_EINVAL, why);
+        max_depth = std::max(max_depth, r.depth);
+        for (int k = 0; k < nk; ++k) top.push_back({kids[k], r.depth + 1});
     }
-    {   // index order of siblings: (min, max) triangle index under every inner node, children before parents
+    const size_t n_roots = top.size() - head;
+    std::vector<const char*> why_of(n_roots, nullptr);
+    std::vector<uint32_t> depth_of(n_roots, 0);
+    par::forTasks(n_roots, threads, [&](size_t ti) {
+        std::vector<Ref> st{top[head + ti]};
         std::vector<uint32_t> order;
-        order.reserve(s->n_nodes);
-        std::vector<uint32_t> st{0u};
         while (!st.empty()) {
-            const uint32_t n = st.back();
+            const Ref r = st.back();
             st.pop_back();
-            order.push_back(n);
-            if (!(s->nodes[n].child0 & TRT_LEAF_BIT)) st.push_back(s->nodes[n].child0);
-            if (!(s->nodes[n].child1 & TRT_LEAF_BIT)) st.push_back(s->nodes[n].child1);
+            uint32_t kids[2];
+            int nk;
+            if (const char* why = visit(r.node, r.depth, kids, nk)) { why_of[ti] = why; return; }
+            order.push_back(r.node);
+            depth_of[ti] = std::max(depth_of[ti], r.depth);
+            for (int k = 0; k < nk; ++k) st.push_back({kids[k], r.depth + 1});
         }
-        std::vector<uint32_t> lo(s->n_nodes, 0xFFFFFFFFu), hi(s->n_nodes, 0u);
-        std::vector<uint8_t> has(s->n_nodes, 0);
-        for (size_t k = order.size(); k-- > 0;) {
-            const uint32_t n = order[k];
-            uint32_t clo[2], chi[2];
-            bool chas[2];
-            const uint32_t ch[2] = {s->nodes[n].child0, s->nodes[n].child1};
-            for (int c = 0; c < 2; ++c) {
-                if (ch[c] & TRT_LEAF_BIT) {
-                    const uint32_t first = TRT_LEAF_FIRST(ch[c]), count = TRT_LEAF_COUNT(ch[c]);
-                    chas[c] = count != 0;
-                    clo[c] = first;
-                    chi[c] = first + count - (count ? 1u : 0u);
-                } else {
-                    chas[c] = has[ch[c]] != 0;
-                    clo[c] = lo[ch[c]];
-                    chi[c] = hi[ch[c]];
-                }
-            }
-            if (chas[0] && chas[1] && !(chi[0] < clo[1])) return fail(TRT_EINVAL, "bvh: triangles under child0 must precede those under child1 (post-BVH order)");
-            has[n] = chas[0] || chas[1];
-            lo[n] = std::min(chas[0] ? clo[0] : 0xFFFFFFFFu, chas[1] ? clo[1] : 0xFFFFFFFFu);
-            hi[n] = std::max(chas[0] ? chi[0] : 0u, chas[1] ? chi[1] : 0u);
-        }
+        for (size_t k = order.size(); k-- > 0;)
+            if (const char* why = order_rule(order[k])) { why_of[ti] = why; return; }
+    });
+    for (size_t ti = 0; ti < n_roots; ++ti) {
+        if (why_of[ti]) return fail(TRT_EINVAL, why_of[ti]);
+        max_depth = std::max(max_depth, depth_of[ti]);
     }
+    for (size_t k = head; k-- > 0;)
+        if (const char* why = order_rule(top[k].node)) return fail(TRT_EINVAL, why);
     *depth_out = max_depth;
     return TRT_OK;
 }
@@ -396,7 +422,7 @@ int buildSceneImage(const trt_scene* s, SceneImage& im)
     im.threads = par::defaultThreads();
     if (const char* e = std::getenv("TRT_HOST_THREADS")) im.threads = (unsigned)std::min(256, std::max(1, std::atoi(e)));
     Lap lap{im.dbg};
-    if (int e = validateBvh(s, &im.bvh2_depth)) return e;
+    if (int e = validateBvh(s, &im.bvh2_depth, im.threads)) return e;
     lap("checks, validateBvh");
 
     // the wave-uniform walk needs a 32-bit reach mask, and it evaluates the nodes in index order: every inner child must
