@@ -1,5 +1,6 @@
 # Builds everything in-tree (the .so files travel to the GPU box with the snapshot).
 #   libtrt_hip.so   — the C-ABI hot path (include/trt.h), HIP for gfx950
+#   libtrt_lbvh.so  — GPU BVH builder (include/trt_build.h), HIP for gfx950; not needed by the render path
 #   libtrt_host.so  — loaders / BVH / PNG (include/trt_host.h), plain C++
 #   tinyrt          — CLI: loaders -> render() -> PNG (the reference's main())
 #   oracle/liboracle.so — CPU restatement used by tests/ and bench.py only
@@ -28,11 +29,12 @@ HOST_HDR := $(wildcard $(PKG)/host/*.h) include/trt.h include/trt_host.h include
 HIP_SRC := $(PKG)/csrc/trt_api.hip
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h include/trt_exact.h
 
-.PHONY: all host hip oracle cli hostsim variants probe exactcheck clean
-all: host hip oracle hostsim cli exactcheck
+.PHONY: all host hip lbvh oracle cli hostsim variants probe exactcheck clean
+all: host hip lbvh oracle hostsim cli exactcheck
 
 host: $(OUT)/libtrt_host.so
 hip: $(OUT)/libtrt_hip.so
+lbvh: $(OUT)/libtrt_lbvh.so
 cli: $(OUT)/tinyrt
 oracle:
 	$(MAKE) -C oracle
@@ -48,6 +50,10 @@ $(OUT)/libtrt_host.so: $(HOST_SRC) $(HOST_HDR)
 $(OUT)/libtrt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+$(OUT)/libtrt_lbvh.so: $(PKG)/csrc/trt_lbvh.hip include/trt.h include/trt_build.h
+	@mkdir -p $(OUT)
+	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wextra -Wno-unused-parameter -Iinclude -shared -o $@ $(PKG)/csrc/trt_lbvh.hip
 
 $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -fopenmp -Wl,-rpath,'$$ORIGIN'

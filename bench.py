@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--tris", type=int, default=None, help="triangle count of the synthetic scenes")
     ap.add_argument("--leaf", type=int, default=None, help="triangles per BVH leaf (the reference uses 8); default: 8 for scenes of <= 64 triangles, else 2")
+    ap.add_argument("--builder", default="auto", choices=["auto", "sweep", "binned", "lbvh"], help="BVH builder: the host SAH builders, or the GPU LBVH builder of include/trt_build.h")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=None)
     ap.add_argument("--mem-gb", type=float, default=0.0, help="HBM budget for path state (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,12 +106,12 @@ class Bench:
             self.dist.barrier()
             self.torch.cuda.synchronize()
 
-    def measure(self, scene_name, width, height, spp, steps, warmup, seed, leaf=None, tris=None, base_flags=0, also_overlap=False, save_png=None):
+    def measure(self, scene_name, width, height, spp, steps, warmup, seed, leaf=None, tris=None, base_flags=0, also_overlap=False, save_png=None, builder=None):
         """Counting render (untimed), warm-up, then `steps` timed renders of one workload.  Returns the result fields."""
         T, D, torch, a = self.T, self.D, self.torch, self.a
         world, rank, local_rank, dist = self.world, self.rank, self.local_rank, self.dist
         t0 = time.time()
-        scene = T.Scene.named(scene_name, width, height, leaf_num=leaf, n=tris)
+        scene = T.Scene.named(scene_name, width, height, leaf_num=leaf, n=tris, builder=builder or a.builder)
         t_load = time.time() - t0
         renderer = T.Renderer(scene, local_rank)
         budget = int(a.mem_gb * (1 << 30))
@@ -225,7 +226,7 @@ class Bench:
                 "value": round(mrays, 2), "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
                 "data": f"scene '{scene_name}' ({WORKLOADS[scene_name]}), counter RNG seed {seed:#x}",
                 "config": {"workload": f"{WORKLOADS[scene_name]}, {width}x{height}, {spp} spp", "scene": scene_name, "width": width,
-                           "height": height, "spp": spp, "triangles": scene.info["n_triangles"], "bvh_nodes": scene.arrays()["n_nodes"],
+                           "height": height, "spp": spp, "triangles": scene.info["n_triangles"], "bvh_nodes": scene.arrays()["n_nodes"], "bvh_builder": builder or a.builder,
                            "leaf_num": leaf if leaf is not None else T.default_leaf(scene_name, scene.info["n_triangles"]),
                            "inner_node_bytes": st_count.inner_node_bytes,
                            "overlap_passes": bool(base_flags & T.TRT_FLAG_OVERLAP), "fixed_nee": bool(a.fixed_nee),

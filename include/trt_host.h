@@ -46,7 +46,14 @@ int trth_scene_add_blob(trth_scene* s, uint32_t seed, uint64_t n_min_faces);
 /* buildBVH(scene.triangles, 0, n-1, leaf_num) (main.cpp:76) + flattening. */
 int trth_scene_build(trth_scene* s, int leaf_num, int builder);
 
-/* Valid after trth_scene_build; owned by the scene. */
+/* The other way to a built scene: a tree from another builder (the GPU builder of trt_build.h).  trth_scene_vertices copies the
+ * vertices of the triangles in their current order (n_triangles * 9 floats: what that builder takes); trth_scene_adopt_bvh
+ * reorders the triangles — position i gets the triangle that stood at order[i], the in-place sort of buildBVH (bvh.cpp:16-144) as
+ * one permutation — installs the nodes and flattens.  The tree is not checked here: trt_create validates every tree it is given. */
+int trth_scene_vertices(const trth_scene* s, float* out, uint64_t capacity_floats);
+int trth_scene_adopt_bvh(trth_scene* s, const trt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* order, uint32_t depth);
+
+/* Valid after trth_scene_build / trth_scene_adopt_bvh; owned by the scene. */
 const trt_scene* trth_scene_flat(const trth_scene* s);
 
 /* info[0..7] = width, height, n_vertices, n_vn, n_vt, n_triangles, n_materials, n_lights */

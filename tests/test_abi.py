@@ -32,6 +32,25 @@ def test_host_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
 
 
+def test_builder_library_exports_every_declared_symbol_and_fails_loudly_without_a_device():
+    lib = C.CDLL(os.path.join(_abi.LIB_DIR, "libtrt_lbvh.so"))
+    names = _declared("trt_build.h", "trt_build_")
+    assert set(names) == set(_abi.BUILD_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), n
+    # argument checks come before any device is touched
+    b = _abi.load_build()
+    nodes = (_abi.BvhNode * 4)()
+    order = (C.c_uint32 * 4)()
+    nn = C.c_uint32(0)
+    v = (C.c_float * 36)()
+    assert b.trt_build_lbvh(v, 4, 0, 0, nodes, 4, C.byref(nn), order, None, None) == 1 and b"leaf_num" in b.trt_build_last_error()
+    assert b.trt_build_lbvh(v, 4, 2, 0, None, 4, C.byref(nn), order, None, None) == 1 and b"null" in b.trt_build_last_error()
+    import torch
+    if not torch.cuda.is_available():
+        assert b.trt_build_lbvh(v, 4, 2, 0, nodes, 4, C.byref(nn), order, None, None) == 4 and b"HIP device" in b.trt_build_last_error()
+
+
 def test_oracle_exports_every_declared_symbol():
     lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
     text = open(os.path.join(ROOT, "oracle", "oracle.h")).read()
@@ -127,7 +146,7 @@ def test_validation_on_several_host_threads_finds_faults_deep_in_a_big_tree(monk
     h = C.c_void_p()
     for threads in ("1", "8"):
         monkeypatch.setenv("TRT_HOST_THREADS", threads)
-        for what, needle in (("index", b"out of range"), ("cycle", b"twice"), ("order", b"post-BVH order"), ("shared", b"two leaves"), ("none", None)):
+        for what, needle in (("index", b"out of range"), ("cycle", b"twice"), ("order", b"post-BVH order"), ("shared", (b"two leaves", b"post-BVH order")), ("none", None)):
             C.memmove(nodes, f.nodes, C.sizeof(BvhNode) * f.n_nodes)
             n = inner[len(inner) // 2]
             if what == "index":
@@ -144,5 +163,7 @@ def test_validation_on_several_host_threads_finds_faults_deep_in_a_big_tree(monk
                 if rc == 0:
                     lib.trt_destroy(h)
             else:
-                assert rc == 1 and needle in lib.trt_last_error(), (threads, what, rc, lib.trt_last_error())
+                # (a triangle range shared by two leaves also breaks the index order of some ancestor's children: whichever walk gets there first)
+                needles = needle if isinstance(needle, tuple) else (needle,)
+                assert rc == 1 and any(x in lib.trt_last_error() for x in needles), (threads, what, rc, lib.trt_last_error())
     s.close()

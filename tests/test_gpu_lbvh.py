@@ -1,0 +1,102 @@
+"""The GPU BVH builder (include/trt_build.h, libtrt_lbvh.so) — MI355X only.
+
+What is checked: the tree it returns is one trt_create accepts (validateBvh: indices, every triangle in exactly one leaf, post-BVH
+triangle order), with leaves of <= leaf_num triangles and nested boxes (so it qualifies for the 8-wide nodes); the triangles it
+orders are a permutation; and — the parity bar of every caller's tree — the HIP path on that tree is bit-identical to the oracle
+walking the same tree, hits and images.  Quality is reported against the host SAH builder (node visits per ray), not asserted to
+a bar an LBVH cannot meet: it is the fast builder, not the good one.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import raygen
+import tinyraytracing_amd as T
+
+pytestmark = pytest.mark.gpu
+LEAF_BIT = 0x80000000
+
+
+def _tree_facts(s):
+    f = s.flat.contents
+    nodes = np.ctypeslib.as_array(C.cast(f.nodes, C.POINTER(C.c_uint32)), shape=(f.n_nodes, 16))
+    refs = nodes[:, 12:14].reshape(-1)
+    leaves = refs[(refs & LEAF_BIT) != 0]
+    counts = (leaves >> 27) & 15
+    return f.n_nodes, int(counts.max()), int(counts.sum())
+
+
+@pytest.mark.parametrize("name,kw,leaf", [("veach-mis", {}, 2), ("staircase", {}, 2), ("staircase", {}, 8), ("soup", {"n": 50000}, 1), ("blob", {"n": 150000}, 2)])
+def test_lbvh_tree_is_valid_and_renders_like_the_oracle_on_it(name, kw, leaf):
+    s = T.Scene.named(name, 96, 54, leaf_num=leaf, builder="lbvh", **kw)
+    n_tris = s.info["n_triangles"]
+    n_nodes, biggest_leaf, in_leaves = _tree_facts(s)
+    assert biggest_leaf <= leaf and in_leaves == n_tris and n_nodes <= max(n_tris, 2) - 1
+    r = T.Renderer(s, 0)  # trt_create: validateBvh, the collapses
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(100000, lo - 1, hi + 1, seed=5)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    t1, tri1, uv1 = r.trace_closest(org, dirs)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+    p = T.make_params(96, 54, 4, 321)
+    img, st = r.render(p)
+    ref, ost = O.render(s.flat, p)
+    assert np.array_equal(img, ref)
+    assert (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
+    if leaf <= 3:
+        assert st.inner_node_bytes == 80, "nested boxes, leaves of <= 3: the tree takes the 8-wide nodes"
+    r.close()
+    s.close()
+
+
+def test_lbvh_on_coincident_triangles_and_tiny_inputs():
+    """Equal Morton codes (every triangle twice: the soup added two times with one seed) are told apart by position: a valid tree, the
+    same image as the oracle on it.  A scene that fits one leaf gets the root with an empty second child, like the host builder."""
+    d = os.path.join(T.SCENES_DIR, "back")
+    s = T.Scene.load(os.path.join(d, "back.xml"), os.path.join(d, "back.obj"), os.path.join(d, "back.mtl"), d, 64, 36)
+    s._check(s._lib.trth_scene_drop_tris(s._h, 6, 12))
+    s._check(s._lib.trth_scene_add_soup(s._h, 7, 3000))
+    s._check(s._lib.trth_scene_add_soup(s._h, 7, 3000))
+    s.build_bvh(2, "lbvh")
+    r = T.Renderer(s, 0)
+    p = T.make_params(64, 36, 4, 9)
+    img, _ = r.render(p)
+    ref, _ = O.render(s.flat, p)
+    assert np.array_equal(img, ref)
+    r.close()
+    s.close()
+    p = T.make_params(64, 36, 4, 9)
+    for drop, leaf, one_leaf in ((0, 15, False), (12, 15, True)):
+        s2 = T.Scene.load(os.path.join(d, "back.xml"), os.path.join(d, "back.obj"), os.path.join(d, "back.mtl"), d, 64, 36)
+        if drop:
+            s2._check(s2._lib.trth_scene_drop_tris(s2._h, 6, drop))
+        s2.build_bvh(leaf, "lbvh")
+        n_nodes, biggest, total = _tree_facts(s2)
+        assert biggest <= leaf and total == s2.info["n_triangles"]
+        if one_leaf:
+            assert s2.info["n_triangles"] <= leaf and n_nodes == 1
+        r = T.Renderer(s2, 0)
+        img, _ = r.render(p)
+        assert np.array_equal(img, O.render(s2.flat, p)[0])
+        r.close()
+        s2.close()
+
+
+def test_lbvh_quality_and_speed_are_on_record(capsys):
+    """Node visits and triangle tests per ray of the LBVH tree against the host SAH tree on the 150 k-triangle mesh (COUNT kernels), and the
+    builder's own time: printed for the record (tools/lbvh_cost.py does the 10 M case), with a loose sanity bound only."""
+    res = {}
+    for b in ("auto", "lbvh"):
+        s = T.Scene.named("blob", 320, 180, leaf_num=2, builder=b, n=150000)
+        r = T.Renderer(s, 0)
+        _, st = r.render(T.make_params(320, 180, 4, 11, flags=T.TRT_FLAG_COUNT))
+        rays = st.rays_camera + st.rays_shadow + st.rays_indirect
+        res[b] = ((st.inner_visits[0] + st.inner_visits[1]) / rays, (st.tri_tests[0] + st.tri_tests[1]) / rays, getattr(s, "build_ms", None))
+        r.close()
+        s.close()
+    with capsys.disabled():
+        print(f"\nblob-150k: visits / tests per ray  SAH {res['auto'][0]:.2f} / {res['auto'][1]:.2f}   LBVH {res['lbvh'][0]:.2f} / {res['lbvh'][1]:.2f}   LBVH build (device ms, call ms) {res['lbvh'][2]}")
+    assert res["lbvh"][0] < 3.0 * res["auto"][0]

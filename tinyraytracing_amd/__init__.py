@@ -91,9 +91,29 @@ class Scene:
         if rc != 0:
             raise TrtError(self._lib.trth_last_error().decode())
 
-    def build_bvh(self, leaf_num=DEFAULT_LEAF, builder="auto"):
-        """BVHNode* root = buildBVH(scene.triangles, 0, n-1, leaf_num) (main.cpp:76 passes 8) + flattening."""
-        self._check(self._lib.trth_scene_build(self._h, int(leaf_num), _BUILDERS[builder]))
+    def build_bvh(self, leaf_num=DEFAULT_LEAF, builder="auto", device=0):
+        """BVHNode* root = buildBVH(scene.triangles, 0, n-1, leaf_num) (main.cpp:76 passes 8) + flattening.
+        builder: "sweep" / "binned" / "auto" = the host builders (exact SAH up to 64 k triangles, 32-bin SAH above); "lbvh" = the GPU
+        builder of include/trt_build.h on `device` (Morton order + radix tree; `self.build_ms` = (device ms, whole call ms))."""
+        if builder == "lbvh":
+            lib = _abi.load_build()
+            n = self.info["n_triangles"]
+            v = np.empty(max(n, 1) * 9, np.float32)
+            self._check(self._lib.trth_scene_vertices(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), v.size))
+            cap = max(n, 2) - 1
+            node_bytes = np.empty(cap * C.sizeof(_abi.BvhNode), np.uint8)  # (a ctypes array of 10 M nodes would be zeroed first)
+            nodes = C.cast(node_bytes.ctypes.data, C.POINTER(_abi.BvhNode))
+            order = np.empty(max(n, 1), np.uint32)
+            n_nodes, depth = C.c_uint32(0), C.c_uint32(0)
+            ms = (C.c_double * 2)()
+            rc = lib.trt_build_lbvh(v.ctypes.data_as(C.POINTER(C.c_float)), n, int(leaf_num), int(device), nodes, cap, C.byref(n_nodes),
+                                    order.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(depth), ms)
+            if rc != 0:
+                raise TrtError(f"trt_build_lbvh failed ({rc}): {lib.trt_build_last_error().decode()}")
+            self.build_ms = (ms[0], ms[1])
+            self._check(self._lib.trth_scene_adopt_bvh(self._h, nodes, n_nodes.value, order.ctypes.data_as(C.POINTER(C.c_uint32)), depth.value))
+        else:
+            self._check(self._lib.trth_scene_build(self._h, int(leaf_num), _BUILDERS[builder]))
         self._built = True
         return self
 

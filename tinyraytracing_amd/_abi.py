@@ -84,13 +84,32 @@ class Stats(C.Structure):
 # the symbols include/trt.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = ["trt_rows_selected", "trt_create", "trt_render", "trt_render_device", "trt_render_samples", "trt_trace_closest",
                "trt_destroy", "trt_last_error", "trt_abi_version", "trt_group_create", "trt_group_render", "trt_group_render_device", "trt_group_size", "trt_group_destroy"]
+BUILD_SYMBOLS = ["trt_build_lbvh", "trt_build_last_error"]
 HOST_SYMBOLS = ["trth_scene_load", "trth_scene_load_opts", "trth_scene_drop_tris", "trth_scene_add_soup", "trth_scene_add_blob",
-                "trth_scene_build", "trth_scene_flat", "trth_scene_info", "trth_scene_light_area",
+                "trth_scene_build", "trth_scene_vertices", "trth_scene_adopt_bvh", "trth_scene_flat", "trth_scene_info", "trth_scene_light_area",
                 "trth_scene_material_name", "trth_scene_free", "trth_tonemap", "trth_write_png",
                 "trth_write_png_bytes", "trth_decode_jpeg", "trth_abi_sizes", "trth_last_error"]
 
 _hip = None
 _host = None
+_build = None
+
+
+def load_build():
+    """Loads the GPU BVH builder (include/trt_build.h).  A library of its own: the render path does not need it."""
+    global _build
+    if _build is not None:
+        return _build
+    _bind_to_torch_hip_runtime()
+    path = os.path.join(LIB_DIR, "libtrt_lbvh.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make lbvh`")
+    lib = C.CDLL(path)
+    lib.trt_build_last_error.restype = C.c_char_p
+    lib.trt_build_lbvh.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_int, C.c_int, C.POINTER(BvhNode), C.c_uint32, C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    _build = lib
+    return lib
 
 
 def load_host():
@@ -110,6 +129,8 @@ def load_host():
     lib.trth_scene_add_soup.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     lib.trth_scene_add_blob.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     lib.trth_scene_build.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.trth_scene_vertices.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint64]
+    lib.trth_scene_adopt_bvh.argtypes = [C.c_void_p, C.POINTER(BvhNode), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]
     lib.trth_scene_flat.restype = C.POINTER(SceneFlat)
     lib.trth_scene_flat.argtypes = [C.c_void_p]
     lib.trth_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]

@@ -1,0 +1,455 @@
+// trt_lbvh.hip — the GPU BVH builder behind include/trt_build.h (libtrt_lbvh.so, gfx950).
+//
+// Role: buildBVH(scene.triangles, 0, n - 1, leaf_num) of the reference (bvh.cpp:16-144, called at main.cpp:76) for scenes of
+// millions of triangles, as a linear BVH built entirely on the device:
+//   K1 k_prim_boxes   triangle -> its box (32 B) and, reduced per grid, the bounds of the box centres
+//   K2 k_morton       box centre -> 63-bit Morton code (21 bits per axis in the centre bounds), value = triangle index
+//      rocprim::radix_sort_pairs (64-bit keys, one pass over the 63 bits that are used)
+//   K3 k_hierarchy    inner node i of the radix tree over the sorted codes from i alone (Karras 2012: direction, range by
+//                     doubling + bisection on the common-prefix length, split by bisection; equal codes are told apart by
+//                     their position, so runs of duplicates become balanced subtrees)
+//   K4 k_boxes_up     boxes bottom-up: one thread per triangle climbs, the second arrival at a node (acquire/release counter)
+//                     merges its children and goes on; every thread ends at a node it reaches first or at the root
+//   K5 k_survive + rocprim::exclusive_scan + k_emit   inner nodes that hold more than leaf_num triangles become the flat
+//                     64-B nodes of trt.h (a radix-tree node covers a contiguous range of the sorted order, so a subtree of
+//                     <= leaf_num triangles IS a leaf (first, count)); boxes padded like the reference's (bvh.cpp:31-40)
+//   K6 k_depth        inner nodes on the longest root path
+// All HBM-bound streaming or gather work, a few milliseconds for 10 M triangles; the call is dominated by moving the vertices
+// in (360 MB) and the nodes out (< 640 MB) over PCIe.  No MFMA, no LDS tiling: nothing here is a contraction.
+#include <hip/hip_runtime.h>
+
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "trt.h"
+#include "trt_build.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPC(expr)                                                                                                              \
+    do {                                                                                                                        \
+        hipError_t e_ = (expr);                                                                                                 \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? TRT_ENOMEM : TRT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevMem {  // frees what a failed call leaves behind
+    std::vector<void*> p;
+    ~DevMem() { for (void* q : p) (void)hipFree(q); }
+    template <class T>
+    hipError_t alloc(T** out, size_t count)
+    {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) { p.push_back(q); *out = static_cast<T*>(q); }
+        return e;
+    }
+};
+
+constexpr uint32_t LEAF = 0x80000000u;  // in child references of the radix tree: a single triangle (sorted position), else an inner node
+constexpr float PAD = 0.001f;           // bvh.cpp:31-40
+
+// order-preserving map float -> uint32 (for atomicMin / atomicMax on floats of either sign)
+__device__ inline uint32_t fkey(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float fkeyInv(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+struct Box8 {  // (lo.xyz, hi.x) (hi.yz, -, -)
+    float4 a, b;
+};
+
+// K1: bounds[0..2] = min of the box centres (keys), bounds[3..5] = max
+__global__ __launch_bounds__(256) void k_prim_boxes(const float* __restrict__ tri_v, uint32_t n, Box8* __restrict__ pbox, uint32_t* __restrict__ bounds)
+{
+    float cmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float* v = tri_v + (size_t)i * 9;
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(v[a], fminf(v[3 + a], v[6 + a]));
+            hi[a] = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+            const float c = 0.5f * lo[a] + 0.5f * hi[a];
+            cmin[a] = fminf(cmin[a], c);
+            cmax[a] = fmaxf(cmax[a], c);
+        }
+        Box8 b;
+        b.a = make_float4(lo[0], lo[1], lo[2], hi[0]);
+        b.b = make_float4(hi[1], hi[2], 0.0f, 0.0f);
+        pbox[i] = b;
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            cmin[a] = fminf(cmin[a], __shfl_xor(cmin[a], off));
+            cmax[a] = fmaxf(cmax[a], __shfl_xor(cmax[a], off));
+        }
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bounds[a], fkey(cmin[a]));
+            atomicMax(&bounds[3 + a], fkey(cmax[a]));
+        }
+    }
+}
+
+__device__ inline unsigned long long spread21(unsigned long long x)
+{
+    x &= 0x1FFFFFull;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+struct CentreFrame {
+    float lo[3], scale[3];  // scale = 2^21 / extent (0 for a flat axis)
+};
+
+// K2
+__global__ __launch_bounds__(256) void k_morton(const Box8* __restrict__ pbox, uint32_t n, CentreFrame f, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Box8 b = pbox[i];
+    const float c[3] = {0.5f * b.a.x + 0.5f * b.a.w, 0.5f * b.a.y + 0.5f * b.b.x, 0.5f * b.a.z + 0.5f * b.b.y};
+    unsigned long long q[3];
+    for (int a = 0; a < 3; ++a) {
+        float t = (c[a] - f.lo[a]) * f.scale[a];
+        t = fminf(fmaxf(t, 0.0f), 2097151.0f);  // (a NaN centre lands on 0)
+        q[a] = (unsigned long long)(uint32_t)t;
+    }
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    vals[i] = i;
+}
+
+// common-prefix length of the codes at sorted positions i and j (-1 outside the array); equal codes go on with the positions
+__device__ inline int delta(const unsigned long long* __restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+}
+
+// K3: inner node i in [0, n - 2]; node 0 is the root
+__global__ __launch_bounds__(256) void k_hierarchy(const unsigned long long* __restrict__ keys, uint32_t n_prims, uint32_t* __restrict__ left, uint32_t* __restrict__ right,
+                                                   uint32_t* __restrict__ first, uint32_t* __restrict__ last, uint32_t* __restrict__ parent, uint32_t* __restrict__ leaf_parent)
+{
+    const int n = (int)n_prims;
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;  // (ends: outside the array delta is -1 <= dmin)
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const uint32_t lc = (lo == gamma) ? (LEAF | (uint32_t)gamma) : (uint32_t)gamma;
+    const uint32_t rc = (hi == gamma + 1) ? (LEAF | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+    left[i] = lc;
+    right[i] = rc;
+    first[i] = (uint32_t)lo;
+    last[i] = (uint32_t)hi;
+    if (lc & LEAF) leaf_parent[gamma] = (uint32_t)i; else parent[gamma] = (uint32_t)i;
+    if (rc & LEAF) leaf_parent[gamma + 1] = (uint32_t)i; else parent[gamma + 1] = (uint32_t)i;
+    if (i == 0) parent[0] = 0xFFFFFFFFu;
+}
+
+__device__ inline void loadBoxCoherent(const Box8* p, float out[6])
+{
+    // written by another thread of this launch: read past the L1 (the acquire of the counter orders it)
+    const float* f = reinterpret_cast<const float*>(p);
+    out[0] = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[1] = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[2] = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[3] = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[4] = __hip_atomic_load(f + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[5] = __hip_atomic_load(f + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// K4: nbox[i] = bounds of inner node i.  arrivals[] starts at 0.
+__global__ __launch_bounds__(256) void k_boxes_up(const Box8* __restrict__ pbox, const uint32_t* __restrict__ order, uint32_t n_prims, const uint32_t* __restrict__ left,
+                                                  const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent,
+                                                  Box8* nbox, uint32_t* arrivals)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_prims || n_prims < 2) return;
+    uint32_t node = leaf_parent[p];
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {  // (a root path is at most 63 + 32 nodes long; the guard only bounds a corrupted tree)
+        // the second thread to arrive finds both children complete; the first one is done
+        if (__hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        const uint32_t ch[2] = {left[node], right[node]};
+        for (int k = 0; k < 2; ++k) {
+            float b[6];
+            if (ch[k] & LEAF) {
+                const Box8 x = pbox[order[ch[k] & ~LEAF]];
+                b[0] = x.a.x; b[1] = x.a.y; b[2] = x.a.z; b[3] = x.a.w; b[4] = x.b.x; b[5] = x.b.y;
+            } else {
+                loadBoxCoherent(nbox + ch[k], b);
+            }
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], b[a]); hi[a] = fmaxf(hi[a], b[3 + a]); }
+        }
+        float* o = reinterpret_cast<float*>(nbox + node);
+        __hip_atomic_store(o + 0, lo[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, lo[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 2, lo[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 3, hi[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 4, hi[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 5, hi[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t up = parent[node];
+        if (up == 0xFFFFFFFFu) return;  // the root
+        node = up;
+    }
+}
+
+// K5a: 1 for the inner nodes that stay nodes (more than leaf_num triangles below them)
+__global__ __launch_bounds__(256) void k_survive(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, uint32_t n_inner, uint32_t leaf_num, uint32_t* __restrict__ keep)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_inner) keep[i] = (last[i] - first[i] + 1u > leaf_num) ? 1u : 0u;
+}
+
+// K5b
+__global__ __launch_bounds__(256) void k_emit(const Box8* __restrict__ pbox, const uint32_t* __restrict__ order, const Box8* __restrict__ nbox, const uint32_t* __restrict__ left,
+                                              const uint32_t* __restrict__ right, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                              const uint32_t* __restrict__ keep, const uint32_t* __restrict__ new_index, uint32_t n_inner, trt_bvh_node* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner || !keep[i]) return;
+    trt_bvh_node nd;
+    const uint32_t ch[2] = {left[i], right[i]};
+    for (int k = 0; k < 2; ++k) {
+        Box8 x;
+        uint32_t ref;
+        if (ch[k] & LEAF) {
+            const uint32_t pos = ch[k] & ~LEAF;
+            x = pbox[order[pos]];
+            ref = TRT_MAKE_LEAF(pos, 1u);
+        } else {
+            x = nbox[ch[k]];
+            ref = keep[ch[k]] ? new_index[ch[k]] : TRT_MAKE_LEAF(first[ch[k]], last[ch[k]] - first[ch[k]] + 1u);
+        }
+        float* lo = k ? nd.lo1 : nd.lo0;
+        float* hi = k ? nd.hi1 : nd.hi0;
+        lo[0] = x.a.x - PAD; lo[1] = x.a.y - PAD; lo[2] = x.a.z - PAD;
+        hi[0] = x.a.w + PAD; hi[1] = x.b.x + PAD; hi[2] = x.b.y + PAD;
+        if (k) nd.child1 = ref; else nd.child0 = ref;
+    }
+    nd.reserved[0] = nd.reserved[1] = 0;
+    out[new_index[i]] = nd;
+}
+
+// K6: per triangle, the kept inner nodes above it
+__global__ __launch_bounds__(256) void k_depth(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent, const uint32_t* __restrict__ keep, uint32_t n_prims,
+                                               uint32_t* __restrict__ depth_max)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = 0;
+    if (p < n_prims && n_prims >= 2) {
+        uint32_t node = leaf_parent[p];
+        for (uint32_t guard = 0; guard < 4096u && node != 0xFFFFFFFFu; ++guard) {
+            d += keep[node];
+            node = parent[node];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(d, off); d = o > d ? o : d; }
+    if ((threadIdx.x & 63u) == 0 && d) atomicMax(depth_max, d);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* trt_build_last_error(void) { return g_err.c_str(); }
+
+int trt_build_lbvh(const float* tri_v, uint32_t n_tris, int leaf_num, int device, trt_bvh_node* nodes_out, uint32_t node_capacity, uint32_t* n_nodes_out,
+                   uint32_t* order_out, uint32_t* depth_out, double ms_out[2])
+{
+    const auto t_host = std::chrono::steady_clock::now();
+    if (!nodes_out || !n_nodes_out || !order_out || (n_tris && !tri_v)) return fail(TRT_EINVAL, "trt_build_lbvh: null argument");
+    if (leaf_num < 1 || leaf_num > (int)TRT_MAX_LEAF_TRIS) return fail(TRT_EINVAL, "trt_build_lbvh: leaf_num must be in 1..15");
+    if (n_tris > TRT_MAX_TRIS) return fail(TRT_EINVAL, "trt_build_lbvh: too many triangles");
+    if (node_capacity < 1) return fail(TRT_EINVAL, "trt_build_lbvh: node_capacity must be at least 1");
+    if (depth_out) *depth_out = 1;
+    if (ms_out) ms_out[0] = ms_out[1] = 0.0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(TRT_ENODEV, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(TRT_ENODEV, "device ordinal out of range");
+    HIPC(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(TRT_ENODEV, std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName);
+
+    const uint32_t n = n_tris;
+    DevMem mem;
+    float* d_v = nullptr;
+    Box8* d_pbox = nullptr;
+    uint32_t* d_bounds = nullptr;
+    HIPC(mem.alloc(&d_v, (size_t)n * 9));
+    HIPC(mem.alloc(&d_pbox, n));
+    HIPC(mem.alloc(&d_bounds, 8));
+    hipStream_t stream = nullptr;  // the default stream: every call below is ordered on it
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    HIPC(hipEventCreate(&ev0));
+    HIPC(hipEventCreate(&ev1));
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{ev0, ev1};
+    if (n) HIPC(hipMemcpy(d_v, tri_v, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice));
+    {
+        const uint32_t init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+        HIPC(hipMemcpy(d_bounds, init, sizeof(init), hipMemcpyHostToDevice));
+    }
+    HIPC(hipEventRecord(ev0, stream));
+    const uint32_t grid_n = (n + 255u) / 256u;
+    if (n) {
+        hipLaunchKernelGGL(k_prim_boxes, dim3(std::min(grid_n, 2048u)), dim3(256), 0, stream, d_v, n, d_pbox, d_bounds);
+        HIPC(hipGetLastError());
+    }
+
+    // ---- a scene that fits one leaf still gets a root: child0 = every triangle, child1 = an empty leaf (as host/bvh.cpp)
+    if (n <= (uint32_t)leaf_num) {
+        std::vector<Box8> pb(std::max<uint32_t>(n, 1u));
+        if (n) HIPC(hipMemcpy(pb.data(), d_pbox, (size_t)n * sizeof(Box8), hipMemcpyDeviceToHost));
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < n; ++i) {
+            const float b[6] = {pb[i].a.x, pb[i].a.y, pb[i].a.z, pb[i].a.w, pb[i].b.x, pb[i].b.y};
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = i ? std::fmin(lo[a], b[a]) : b[a];
+                hi[a] = i ? std::fmax(hi[a], b[3 + a]) : b[3 + a];
+            }
+        }
+        trt_bvh_node root;
+        std::memset(&root, 0, sizeof(root));
+        for (int a = 0; a < 3; ++a) { root.lo0[a] = root.lo1[a] = lo[a] - PAD; root.hi0[a] = root.hi1[a] = hi[a] + PAD; }
+        root.child0 = TRT_MAKE_LEAF(0, n);
+        root.child1 = TRT_MAKE_LEAF(0, 0);
+        nodes_out[0] = root;
+        *n_nodes_out = 1;
+        for (uint32_t i = 0; i < n; ++i) order_out[i] = i;
+        if (ms_out) ms_out[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host).count();
+        return TRT_OK;
+    }
+
+    const uint32_t n_inner = n - 1;
+    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+    uint32_t *d_vals = nullptr, *d_order = nullptr, *d_left = nullptr, *d_right = nullptr, *d_first = nullptr, *d_last = nullptr, *d_parent = nullptr, *d_leaf_parent = nullptr,
+             *d_arrivals = nullptr, *d_keep = nullptr, *d_new = nullptr, *d_depth = nullptr;
+    Box8* d_nbox = nullptr;
+    HIPC(mem.alloc(&d_keys, n));
+    HIPC(mem.alloc(&d_keys2, n));
+    HIPC(mem.alloc(&d_vals, n));
+    HIPC(mem.alloc(&d_order, n));
+    HIPC(mem.alloc(&d_left, n_inner));
+    HIPC(mem.alloc(&d_right, n_inner));
+    HIPC(mem.alloc(&d_first, n_inner));
+    HIPC(mem.alloc(&d_last, n_inner));
+    HIPC(mem.alloc(&d_parent, n_inner));
+    HIPC(mem.alloc(&d_leaf_parent, n));
+    HIPC(mem.alloc(&d_arrivals, n_inner));
+    HIPC(mem.alloc(&d_keep, n_inner));
+    HIPC(mem.alloc(&d_new, n_inner));
+    HIPC(mem.alloc(&d_depth, 1));
+    HIPC(mem.alloc(&d_nbox, n_inner));
+
+    // the centre bounds are needed on the host to form the Morton frame (six words)
+    uint32_t bk[8];
+    HIPC(hipMemcpy(bk, d_bounds, sizeof(bk), hipMemcpyDeviceToHost));
+    CentreFrame frame;
+    for (int a = 0; a < 3; ++a) {
+        const float lo = fkeyInv(bk[a]), hi = fkeyInv(bk[3 + a]);
+        const float ext = hi - lo;
+        frame.lo[a] = lo;
+        frame.scale[a] = (ext > 0.0f && std::isfinite(ext)) ? 2097152.0f / ext : 0.0f;
+    }
+    hipLaunchKernelGGL(k_morton, dim3(grid_n), dim3(256), 0, stream, d_pbox, n, frame, d_keys, d_vals);
+    HIPC(hipGetLastError());
+    {
+        size_t tmp_bytes = 0;
+        HIPC(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_order, (size_t)n, 0u, 63u, stream));
+        char* d_tmp = nullptr;
+        HIPC(mem.alloc(&d_tmp, tmp_bytes));
+        HIPC(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_order, (size_t)n, 0u, 63u, stream));
+    }
+    const uint32_t grid_i = (n_inner + 255u) / 256u;
+    hipLaunchKernelGGL(k_hierarchy, dim3(grid_i), dim3(256), 0, stream, d_keys2, n, d_left, d_right, d_first, d_last, d_parent, d_leaf_parent);
+    HIPC(hipGetLastError());
+    HIPC(hipMemsetAsync(d_arrivals, 0, (size_t)n_inner * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_boxes_up, dim3(grid_n), dim3(256), 0, stream, d_pbox, d_order, n, d_left, d_right, d_parent, d_leaf_parent, d_nbox, d_arrivals);
+    HIPC(hipGetLastError());
+    hipLaunchKernelGGL(k_survive, dim3(grid_i), dim3(256), 0, stream, d_first, d_last, n_inner, (uint32_t)leaf_num, d_keep);
+    HIPC(hipGetLastError());
+    {
+        size_t tmp_bytes = 0;
+        HIPC(rocprim::exclusive_scan(nullptr, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+        char* d_tmp = nullptr;
+        HIPC(mem.alloc(&d_tmp, tmp_bytes));
+        HIPC(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+    }
+    uint32_t tail[2] = {0, 0};
+    HIPC(hipMemcpy(&tail[0], d_new + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(&tail[1], d_keep + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t n_out = tail[0] + tail[1];
+    if (n_out < 1 || n_out > n_inner) return fail(TRT_EHIP, "trt_build_lbvh: internal error (node count)");
+    if (n_out > node_capacity) return fail(TRT_EINVAL, "trt_build_lbvh: node_capacity too small (n_tris - 1 always suffices)");
+    trt_bvh_node* d_out = nullptr;
+    HIPC(mem.alloc(&d_out, n_out));
+    hipLaunchKernelGGL(k_emit, dim3(grid_i), dim3(256), 0, stream, d_pbox, d_order, d_nbox, d_left, d_right, d_first, d_last, d_keep, d_new, n_inner, d_out);
+    HIPC(hipGetLastError());
+    HIPC(hipMemsetAsync(d_depth, 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_depth, dim3(grid_n), dim3(256), 0, stream, d_parent, d_leaf_parent, d_keep, n, d_depth);
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(ev1, stream));
+    HIPC(hipMemcpy(nodes_out, d_out, (size_t)n_out * sizeof(trt_bvh_node), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(order_out, d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t depth = 0;
+    HIPC(hipMemcpy(&depth, d_depth, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *n_nodes_out = n_out;
+    if (depth_out) *depth_out = depth;
+    if (ms_out) {
+        float ms = 0.0f;
+        HIPC(hipEventElapsedTime(&ms, ev0, ev1));
+        ms_out[0] = ms;
+        ms_out[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host).count();
+    }
+    return TRT_OK;
+}
+
+}  // extern "C"

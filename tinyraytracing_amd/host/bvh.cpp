@@ -6,15 +6,32 @@
 // whole 168-byte Triangle objects three times per node); topology is free to
 // differ — only nearest-hit and the tie rules matter.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
 #include <stdexcept>
 
+#include <omp.h>
+
 #include "scene.h"
 
 namespace trt {
+
+int hostThreads()
+{
+    int t = omp_get_max_threads();
+    if (t > 16) t = 16;
+    if (const char* e = std::getenv("TRT_HOST_THREADS")) t = std::max(1, std::atoi(e));
+    return t;
+}
+
 namespace {
+
+// Threads of the builder: TRT_HOST_THREADS, else min(16, what OpenMP would take).  A GPU box hands a process a share of a big host
+// (16 CPUs of 256 here): a team of 256 threads on that share took 4.7 s for 10 M triangles where 16 take a third of it
+// (profiles/r03_create_cost_10m.txt) — every task wait then waits for threads that are not running.
+int builderThreads() { return hostThreads(); }
 
 struct Box {
     vec3 lo = vec3(std::numeric_limits<float>::max());
@@ -392,7 +409,8 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
     if (triangles.size() > TRT_MAX_TRIS) throw std::runtime_error("buildBVH: too many triangles");
     const size_t n = triangles.size();
     std::vector<Prim> prims(n);
-#pragma omp parallel for schedule(static) if (n >= 100000)
+    const int threads = builderThreads();
+#pragma omp parallel for schedule(static) num_threads(threads) if (n >= 100000)
     for (size_t i = 0; i < n; ++i) {
         const Triangle& t = triangles[i];
         prims[i].box.grow(t.v[0]);
@@ -424,7 +442,7 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
     }
     uint32_t root = 0, deepest = 0;
     out.nodes.reserve(n / (size_t)std::max(1, leaf_num / 2) + 4);
-#pragma omp parallel
+#pragma omp parallel num_threads(threads)
 #pragma omp single
     root = b.build(0, n, 0, out.nodes, deepest);
     if (root != 0) throw std::runtime_error("buildBVH: internal error (root index)");
@@ -432,7 +450,7 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
 
     // reorder the triangles into leaf order (the reference's in-place sorts)
     std::vector<Triangle> sorted(n);
-#pragma omp parallel for schedule(static) if (n >= 100000)
+#pragma omp parallel for schedule(static) num_threads(threads) if (n >= 100000)
     for (size_t i = 0; i < n; ++i) sorted[i] = std::move(triangles[idx[i]]);  // idx is a permutation: every source moved once
     triangles.swap(sorted);
     return out;
@@ -446,7 +464,8 @@ void FlatScene::build(const Scene& scene, const FlatBVH& bvh)
     tri_vt.resize(n * 6);
     tri_mat.resize(n);
     int bad_material = 0;
-#pragma omp parallel for schedule(static) if (n >= 100000)
+    const int threads = builderThreads();
+#pragma omp parallel for schedule(static) num_threads(threads) if (n >= 100000)
     for (size_t i = 0; i < n; ++i) {
         const Triangle& t = scene.triangles[i];
         for (int k = 0; k < 3; ++k) {

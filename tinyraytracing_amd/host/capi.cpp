@@ -91,6 +91,50 @@ int trth_scene_build(trth_scene* s, int leaf_num, int builder)
     return 0;
 }
 
+int trth_scene_vertices(const trth_scene* s, float* out, uint64_t capacity_floats)
+{
+    if (!s || !out) return fail("null argument");
+    const auto& t = s->scene.triangles;
+    if (capacity_floats < (uint64_t)t.size() * 9) return fail("trth_scene_vertices: buffer too small");
+    const size_t n = t.size();
+#pragma omp parallel for schedule(static) num_threads(trt::hostThreads()) if (n >= 100000)
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            out[i * 9 + k * 3 + 0] = t[i].v[k].x;
+            out[i * 9 + k * 3 + 1] = t[i].v[k].y;
+            out[i * 9 + k * 3 + 2] = t[i].v[k].z;
+        }
+    return 0;
+}
+
+int trth_scene_adopt_bvh(trth_scene* s, const trt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* order, uint32_t depth)
+{
+    if (!s || !nodes || !order || n_nodes < 1) return fail("trth_scene_adopt_bvh: null argument");
+    auto& t = s->scene.triangles;
+    const size_t n = t.size();
+    {   // `order` must be a permutation of the triangles
+        std::vector<uint8_t> used(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            if (order[i] >= n || used[order[i]]) return fail("trth_scene_adopt_bvh: order is not a permutation of the triangles");
+            used[order[i]] = 1;
+        }
+    }
+    try {
+        std::vector<trt::Triangle> sorted(n);
+#pragma omp parallel for schedule(static) num_threads(trt::hostThreads()) if (n >= 100000)
+        for (size_t i = 0; i < n; ++i) sorted[i] = std::move(t[order[i]]);  // a permutation: every source moved once
+        t.swap(sorted);
+        s->bvh.nodes.assign(nodes, nodes + n_nodes);
+        s->bvh.depth = depth;
+        s->flat.reset(new trt::FlatScene);
+        s->flat->build(s->scene, s->bvh);
+    } catch (const std::exception& e) {
+        s->flat.reset();
+        return fail(e);
+    }
+    return 0;
+}
+
 const trt_scene* trth_scene_flat(const trth_scene* s)
 {
     if (!s || !s->flat) { fail("scene not built"); return nullptr; }

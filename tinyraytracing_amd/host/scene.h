@@ -44,6 +44,9 @@ public:
     int n_vertices = 0, n_vn = 0, n_vt = 0;
 };
 
+// OpenMP team size of the host-side loops over triangles: TRT_HOST_THREADS, else min(16, OpenMP's default) (bvh.cpp says why).
+int hostThreads();
+
 // ---- BVH ---------------------------------------------------------------------
 enum BvhBuilder {
     BVH_SWEEP_SAH = 0,  // the reference's full-sweep SAH (bvh.cpp:16-144), O(n log^2 n)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# round 3, run 13: the same workloads on the host SAH tree and on the GPU LBVH tree, per kernel
+root=${GRAFT_REPO_ROOT:-/root/repo}
+cd $root
+mkdir -p gpurun_out/r03
+run() { # tag args...
+  tag=$1; shift
+  timeout -k 10 400 python bench.py "$@" --no-cpu-baseline --no-extra --no-overlap-extra > gpurun_out/r03/$tag.json 2> gpurun_out/r03/$tag.err || echo "$tag failed"
+  python - gpurun_out/r03/$tag.json "$tag" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    k = {a: b["ms_per_step"] for a, b in d["kernels_rank0"].items() if b["ms_per_step"]}
+    u = d["simd_utilisation_traversal"]
+    print(f'{sys.argv[2]:30s} {d["value"]:9.1f} Mrays/s {d["ms_per_step"]:9.2f} ms  closest {k.get("trace_closest", 0):8.2f} shade {k.get("shade", 0):7.2f} shadow {k.get("trace_shadow", 0):8.2f} tail {k.get("tail", 0):6.2f} | visits {u["visits_per_ray"]} tests {u["tri_tests_per_ray"]}', flush=True)
+except Exception as e:
+    print(sys.argv[2], "no result", e, flush=True)
+PY
+}
+for b in auto lbvh; do
+  run s13_blob10m_4k_64_$b --scene blob --tris 10000000 --width 3840 --height 2160 --spp 64 --steps 2 --builder $b
+  run s13_blob10m_1080_64_$b --scene blob --tris 10000000 --spp 64 --steps 2 --builder $b
+  run s13_blob2m_1080_64_$b --scene blob --tris 2000000 --spp 64 --steps 2 --builder $b
+  run s13_soup_1080_64_$b --scene soup --spp 64 --steps 2 --builder $b
+  run s13_stair_64_$b --scene staircase --spp 64 --steps 2 --builder $b
+done

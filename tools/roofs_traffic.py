@@ -17,7 +17,12 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     agg = collections.defaultdict(float)
     launches = collections.Counter()
+    newest = {}  # per counter group: the latest run only (gpurun merges a call's files into a directory that may hold an earlier call's)
     for f in glob.glob(d + "/g*/*/*_counter_collection.csv"):
+        g = f[len(d):].split(os.sep)[1]
+        if g not in newest or os.path.getmtime(f) > os.path.getmtime(newest[g]):
+            newest[g] = f
+    for f in newest.values():
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
