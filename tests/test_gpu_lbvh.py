@@ -100,3 +100,26 @@ def test_lbvh_quality_and_speed_are_on_record(capsys):
     with capsys.disabled():
         print(f"\nblob-150k: visits / tests per ray  SAH {res['auto'][0]:.2f} / {res['auto'][1]:.2f}   LBVH {res['lbvh'][0]:.2f} / {res['lbvh'][1]:.2f}   LBVH build (device ms, call ms) {res['lbvh'][2]}")
     assert res["lbvh"][0] < 3.0 * res["auto"][0]
+
+
+def test_config5_ten_million_triangles_built_on_the_device_tiles_vs_oracle():
+    """Config 5's scene at full size with the tree built on the GPU: under a second for the call (the device part: tens of milliseconds),
+    a tree trt_create accepts and collapses into 8-wide nodes, tiles of the 4K image bit-identical to the oracle on the same tree."""
+    d = os.path.join(T.SCENES_DIR, "back")
+    s = T.Scene.load(os.path.join(d, "back.xml"), os.path.join(d, "back.obj"), os.path.join(d, "back.mtl"), d, 3840, 2160)
+    s._check(s._lib.trth_scene_drop_tris(s._h, 6, 12))
+    s._check(s._lib.trth_scene_add_blob(s._h, T.SEED_BLOB, 10_000_000))
+    s.build_bvh(2, "lbvh")
+    assert s.info["n_triangles"] >= 10_000_000
+    assert s.build_ms[1] < 1000.0, s.build_ms
+    r = T.Renderer(s, 0)
+    try:
+        for (x0, y0) in ((1900, 1000), (2300, 1500)):
+            pt = T.make_params(3840, 2160, 16, T.SEED_BLOB, tile=(x0, y0, x0 + 16, y0 + 8))
+            img, st = r.render(pt)
+            ref, ost = O.render(s.flat, pt)
+            assert np.array_equal(img, ref), (x0, y0)
+            assert st.rays == ost.rays and st.inner_node_bytes == 80
+    finally:
+        r.close()
+        s.close()
