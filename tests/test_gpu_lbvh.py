@@ -29,8 +29,13 @@ def _tree_facts(s):
     return f.n_nodes, int(counts.max()), int(counts.sum())
 
 
+@pytest.mark.parametrize("cluster", [None, "0", "48"])
 @pytest.mark.parametrize("name,kw,leaf", [("veach-mis", {}, 2), ("staircase", {}, 2), ("staircase", {}, 8), ("soup", {"n": 50000}, 1), ("blob", {"n": 150000}, 2)])
-def test_lbvh_tree_is_valid_and_renders_like_the_oracle_on_it(name, kw, leaf):
+def test_lbvh_tree_is_valid_and_renders_like_the_oracle_on_it(name, kw, leaf, cluster, monkeypatch):
+    """cluster: TRT_LBVH_CLUSTER — default (the top of the tree by SAH over clusters of <= 2048 triangles), "0" (the radix tree as it is),
+    "48" (many small clusters: a deep SAH top, single-triangle clusters, clusters that are leaves)."""
+    if cluster is not None:
+        monkeypatch.setenv("TRT_LBVH_CLUSTER", cluster)
     s = T.Scene.named(name, 96, 54, leaf_num=leaf, builder="lbvh", **kw)
     n_tris = s.info["n_triangles"]
     n_nodes, biggest_leaf, in_leaves = _tree_facts(s)
@@ -89,8 +94,11 @@ def test_lbvh_quality_and_speed_are_on_record(capsys):
     """Node visits and triangle tests per ray of the LBVH tree against the host SAH tree on the 150 k-triangle mesh (COUNT kernels), and the
     builder's own time: printed for the record (tools/lbvh_cost.py does the 10 M case), with a loose sanity bound only."""
     res = {}
-    for b in ("auto", "lbvh"):
-        s = T.Scene.named("blob", 320, 180, leaf_num=2, builder=b, n=150000)
+    for b in ("auto", "lbvh", "radix"):
+        if b == "radix":
+            os.environ["TRT_LBVH_CLUSTER"] = "0"
+        s = T.Scene.named("blob", 320, 180, leaf_num=2, builder="lbvh" if b == "radix" else b, n=150000)
+        os.environ.pop("TRT_LBVH_CLUSTER", None)
         r = T.Renderer(s, 0)
         _, st = r.render(T.make_params(320, 180, 4, 11, flags=T.TRT_FLAG_COUNT))
         rays = st.rays_camera + st.rays_shadow + st.rays_indirect
@@ -98,8 +106,9 @@ def test_lbvh_quality_and_speed_are_on_record(capsys):
         r.close()
         s.close()
     with capsys.disabled():
-        print(f"\nblob-150k: visits / tests per ray  SAH {res['auto'][0]:.2f} / {res['auto'][1]:.2f}   LBVH {res['lbvh'][0]:.2f} / {res['lbvh'][1]:.2f}   LBVH build (device ms, call ms) {res['lbvh'][2]}")
-    assert res["lbvh"][0] < 3.0 * res["auto"][0]
+        print(f"\nblob-150k: visits / tests per ray  SAH {res['auto'][0]:.2f} / {res['auto'][1]:.2f}   LBVH with SAH top {res['lbvh'][0]:.2f} / {res['lbvh'][1]:.2f}   "
+              f"plain radix tree {res['radix'][0]:.2f} / {res['radix'][1]:.2f}   build (device ms, call ms) {res['lbvh'][2]} / {res['radix'][2]}")
+    assert res["lbvh"][0] < 1.25 * res["auto"][0] and res["radix"][0] < 3.0 * res["auto"][0]
 
 
 def test_config5_ten_million_triangles_built_on_the_device_tiles_vs_oracle():

@@ -295,6 +295,205 @@ __global__ __launch_bounds__(256) void k_depth(const uint32_t* __restrict__ pare
     if ((threadIdx.x & 63u) == 0 && d) atomicMax(depth_max, d);
 }
 
+// ------------------------------------------------------------------ the top of the tree by SAH ----
+// A radix tree splits at fixed planes of the scene box whatever lies on either side; most of what that costs a ray is
+// lost in the upper levels (measured on the CPU with the host builder standing in: SAH above 4096 triangles and plain
+// spatial medians below is within 4-8 % of SAH throughout, medians throughout 25-45 % behind).  So the radix
+// tree is cut into CLUSTERS — the maximal subtrees of <= cluster_size triangles, a few thousand of them for 10 M triangles —,
+// the clusters' boxes and sizes go to the host, an exact sweep-SAH tree over them (cost = area x triangles below) becomes
+// the top of the BVH, and each cluster's radix subtree hangs below its leaf.  The triangle order follows: clusters in the
+// top tree's leaf order, Morton order inside a cluster (a shift per cluster).
+
+// K7: marks the first sorted position of every cluster and notes its root there (LEAF | position for a single triangle)
+__global__ __launch_bounds__(256) void k_cluster_starts(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, const uint32_t* __restrict__ parent,
+                                                        const uint32_t* __restrict__ leaf_parent, uint32_t n_prims, uint32_t cluster_size, uint32_t* __restrict__ start,
+                                                        uint32_t* __restrict__ root_at)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    auto isTop = [&](uint32_t i) { return last[i] - first[i] + 1u > cluster_size; };
+    if (t < n_prims - 1u) {  // inner node t
+        if (!isTop(t) && t != 0u && isTop(parent[t])) { start[first[t]] = 1u; root_at[first[t]] = t; }
+    }
+    if (t < n_prims) {  // triangle at sorted position t
+        if (isTop(leaf_parent[t])) { start[t] = 1u; root_at[t] = LEAF | t; }
+    }
+}
+
+struct ClusterRec {  // what the host needs of a cluster
+    float lo[3], hi[3];
+    uint32_t first, count;
+};
+
+// K8: incl = inclusive scan of start
+__global__ __launch_bounds__(256) void k_cluster_gather(const uint32_t* __restrict__ start, const uint32_t* __restrict__ incl, const uint32_t* __restrict__ root_at,
+                                                        const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, const Box8* __restrict__ pbox,
+                                                        const uint32_t* __restrict__ order, const Box8* __restrict__ nbox, uint32_t n_prims, ClusterRec* __restrict__ rec,
+                                                        uint32_t* __restrict__ croot)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_prims || !start[p]) return;
+    const uint32_t c = incl[p] - 1u, root = root_at[p];
+    const Box8 b = (root & LEAF) ? pbox[order[p]] : nbox[root];
+    ClusterRec r;
+    r.lo[0] = b.a.x; r.lo[1] = b.a.y; r.lo[2] = b.a.z; r.hi[0] = b.a.w; r.hi[1] = b.b.x; r.hi[2] = b.b.y;
+    r.first = p;
+    r.count = (root & LEAF) ? 1u : last[root] - first[root] + 1u;
+    rec[c] = r;
+    croot[c] = root;
+}
+
+// K9a: inner nodes INSIDE clusters that stay nodes
+__global__ __launch_bounds__(256) void k_survive_in_clusters(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, uint32_t n_inner, uint32_t leaf_num,
+                                                             uint32_t cluster_size, uint32_t* __restrict__ keep)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    const uint32_t cnt = last[i] - first[i] + 1u;
+    keep[i] = (cnt > leaf_num && cnt <= cluster_size) ? 1u : 0u;
+}
+
+// K9b: the cluster subtrees as nodes [base, base + kept), triangle positions shifted to the new order
+__global__ __launch_bounds__(256) void k_emit_clusters(const Box8* __restrict__ pbox, const uint32_t* __restrict__ order, const Box8* __restrict__ nbox, const uint32_t* __restrict__ left,
+                                                       const uint32_t* __restrict__ right, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                       const uint32_t* __restrict__ keep, const uint32_t* __restrict__ new_index, const uint32_t* __restrict__ incl,
+                                                       const int32_t* __restrict__ shift, uint32_t n_inner, uint32_t base, trt_bvh_node* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner || !keep[i]) return;
+    const int32_t sh = shift[incl[first[i]] - 1u];
+    trt_bvh_node nd;
+    const uint32_t ch[2] = {left[i], right[i]};
+    for (int k = 0; k < 2; ++k) {
+        Box8 x;
+        uint32_t ref;
+        if (ch[k] & LEAF) {
+            const uint32_t pos = ch[k] & ~LEAF;
+            x = pbox[order[pos]];
+            ref = TRT_MAKE_LEAF((uint32_t)((int32_t)pos + sh), 1u);
+        } else {
+            x = nbox[ch[k]];
+            ref = keep[ch[k]] ? base + new_index[ch[k]] : TRT_MAKE_LEAF((uint32_t)((int32_t)first[ch[k]] + sh), last[ch[k]] - first[ch[k]] + 1u);
+        }
+        float* lo = k ? nd.lo1 : nd.lo0;
+        float* hi = k ? nd.hi1 : nd.hi0;
+        lo[0] = x.a.x - PAD; lo[1] = x.a.y - PAD; lo[2] = x.a.z - PAD;
+        hi[0] = x.a.w + PAD; hi[1] = x.b.x + PAD; hi[2] = x.b.y + PAD;
+        if (k) nd.child1 = ref; else nd.child0 = ref;
+    }
+    nd.reserved[0] = nd.reserved[1] = 0;
+    out[new_index[i]] = nd;
+}
+
+// K10: per cluster: where its root went (kept inner roots only) — and the new triangle order
+__global__ __launch_bounds__(256) void k_cluster_root_index(const uint32_t* __restrict__ croot, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ new_index,
+                                                            uint32_t n_clusters, uint32_t* __restrict__ cidx)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clusters) return;
+    const uint32_t r = croot[c];
+    cidx[c] = (!(r & LEAF) && keep[r]) ? new_index[r] : 0xFFFFFFFFu;
+}
+__global__ __launch_bounds__(256) void k_permute_order(const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl, const int32_t* __restrict__ shift, uint32_t n_prims,
+                                                       uint32_t* __restrict__ order2)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_prims) order2[(uint32_t)((int32_t)p + shift[incl[p] - 1u])] = order[p];
+}
+// K11: kept nodes between a triangle and the root of its cluster, maximum per cluster
+__global__ __launch_bounds__(256) void k_cluster_depth(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent, const uint32_t* __restrict__ keep,
+                                                       const uint32_t* __restrict__ incl, uint32_t n_prims, uint32_t* __restrict__ cdepth)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_prims) return;
+    uint32_t d = 0, node = leaf_parent[p];
+    for (uint32_t guard = 0; guard < 4096u && node != 0xFFFFFFFFu; ++guard) {  // (`keep` is 0 below the leaves' roots and above the cluster's root)
+        d += keep[node];
+        node = parent[node];
+    }
+    if (d) atomicMax(&cdepth[incl[p] - 1u], d);
+}
+
+// ---- host: exact sweep SAH over the clusters, cost = half-area x triangles
+struct TopNode {
+    int32_t child[2];  // >= 0: top node; < 0: ~cluster
+    float lo[2][3], hi[2][3];
+};
+struct TopBuilder {
+    const std::vector<ClusterRec>& cl;
+    std::vector<uint32_t> idx;
+    std::vector<TopNode> nodes;
+    std::vector<uint32_t> leaf_order, top_depth;
+    std::vector<float> suffix_area;
+    std::vector<uint64_t> suffix_count;
+    explicit TopBuilder(const std::vector<ClusterRec>& c) : cl(c), idx(c.size()), top_depth(c.size(), 0), suffix_area(c.size()), suffix_count(c.size())
+    {
+        for (size_t i = 0; i < c.size(); ++i) idx[i] = (uint32_t)i;
+    }
+    static float halfArea(const float* lo, const float* hi)
+    {
+        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x * y + x * z + y * z;
+    }
+    float centre(uint32_t c, int a) const { return 0.5f * cl[c].lo[a] + 0.5f * cl[c].hi[a]; }
+    void sortAxis(size_t lo, size_t hi, int a)
+    {
+        std::sort(idx.begin() + (long)lo, idx.begin() + (long)hi, [&](uint32_t x, uint32_t y) {
+            const float cx = centre(x, a), cy = centre(y, a);
+            return cx < cy || (cx == cy && x < y);
+        });
+    }
+    // returns the reference of the subtree over idx[lo, hi) and its bounds; parents before children
+    int32_t build(size_t lo, size_t hi, uint32_t depth, float* blo, float* bhi)
+    {
+        if (hi - lo == 1) {
+            const uint32_t c = idx[lo];
+            leaf_order.push_back(c);
+            top_depth[c] = depth;
+            for (int a = 0; a < 3; ++a) { blo[a] = cl[c].lo[a]; bhi[a] = cl[c].hi[a]; }
+            return ~(int32_t)c;
+        }
+        const size_t m = hi - lo;
+        float best = std::numeric_limits<float>::max();
+        int best_axis = -1;
+        size_t best_mid = lo + m / 2;
+        for (int a = 0; a < 3 && depth < 48; ++a) {  // (a runaway depth: medians from there on, as in host/bvh.cpp)
+            sortAxis(lo, hi, a);
+            float l3[3] = {3.0e38f, 3.0e38f, 3.0e38f}, h3[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            uint64_t cnt = 0;
+            for (size_t i = m; i-- > 1;) {
+                const ClusterRec& r = cl[idx[lo + i]];
+                for (int k = 0; k < 3; ++k) { l3[k] = std::fmin(l3[k], r.lo[k]); h3[k] = std::fmax(h3[k], r.hi[k]); }
+                cnt += r.count;
+                suffix_area[i] = halfArea(l3, h3);
+                suffix_count[i] = cnt;
+            }
+            for (int k = 0; k < 3; ++k) { l3[k] = 3.0e38f; h3[k] = -3.0e38f; }
+            cnt = 0;
+            for (size_t i = 1; i < m; ++i) {
+                const ClusterRec& r = cl[idx[lo + i - 1]];
+                for (int k = 0; k < 3; ++k) { l3[k] = std::fmin(l3[k], r.lo[k]); h3[k] = std::fmax(h3[k], r.hi[k]); }
+                cnt += r.count;
+                const float cost = halfArea(l3, h3) * (float)cnt + suffix_area[i] * (float)suffix_count[i];
+                if (cost < best) { best = cost; best_axis = a; best_mid = lo + i; }
+            }
+        }
+        if (best_axis < 0) { best_axis = 0; best_mid = lo + m / 2; }
+        if (best_axis != 2) sortAxis(lo, hi, best_axis);
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        float l0[3], h0[3], l1[3], h1[3];
+        const int32_t c0 = build(lo, best_mid, depth + 1, l0, h0);
+        const int32_t c1 = build(best_mid, hi, depth + 1, l1, h1);
+        TopNode& t = nodes[(size_t)me];
+        t.child[0] = c0; t.child[1] = c1;
+        for (int a = 0; a < 3; ++a) {
+            t.lo[0][a] = l0[a]; t.hi[0][a] = h0[a]; t.lo[1][a] = l1[a]; t.hi[1][a] = h1[a];
+            blo[a] = std::fmin(l0[a], l1[a]); bhi[a] = std::fmax(h0[a], h1[a]);
+        }
+        return me;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -414,33 +613,142 @@ int trt_build_lbvh(const float* tri_v, uint32_t n_tris, int leaf_num, int device
     HIPC(hipMemsetAsync(d_arrivals, 0, (size_t)n_inner * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(k_boxes_up, dim3(grid_n), dim3(256), 0, stream, d_pbox, d_order, n, d_left, d_right, d_parent, d_leaf_parent, d_nbox, d_arrivals);
     HIPC(hipGetLastError());
-    hipLaunchKernelGGL(k_survive, dim3(grid_i), dim3(256), 0, stream, d_first, d_last, n_inner, (uint32_t)leaf_num, d_keep);
-    HIPC(hipGetLastError());
-    {
-        size_t tmp_bytes = 0;
-        HIPC(rocprim::exclusive_scan(nullptr, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
-        char* d_tmp = nullptr;
-        HIPC(mem.alloc(&d_tmp, tmp_bytes));
-        HIPC(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+    // ---- the top of the tree by SAH over clusters of the radix tree (TRT_LBVH_CLUSTER triangles at most; 0: the radix tree as it is)
+    uint32_t cluster = 2048;
+    if (const char* e = std::getenv("TRT_LBVH_CLUSTER")) cluster = (uint32_t)std::max(0L, std::atol(e));
+    if (cluster && cluster < (uint32_t)leaf_num) cluster = (uint32_t)leaf_num;
+    uint32_t n_out = 0, depth = 0;
+    if (cluster && n > cluster) {
+        uint32_t *d_start = nullptr, *d_root_at = nullptr, *d_incl = nullptr;
+        HIPC(mem.alloc(&d_start, n));
+        HIPC(mem.alloc(&d_root_at, n));
+        HIPC(mem.alloc(&d_incl, n));
+        HIPC(hipMemsetAsync(d_start, 0, (size_t)n * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_cluster_starts, dim3(grid_n), dim3(256), 0, stream, d_first, d_last, d_parent, d_leaf_parent, n, cluster, d_start, d_root_at);
+        HIPC(hipGetLastError());
+        {
+            size_t tmp_bytes = 0;
+            HIPC(rocprim::inclusive_scan(nullptr, tmp_bytes, d_start, d_incl, (size_t)n, rocprim::plus<uint32_t>(), stream));
+            char* d_tmp = nullptr;
+            HIPC(mem.alloc(&d_tmp, tmp_bytes));
+            HIPC(rocprim::inclusive_scan(d_tmp, tmp_bytes, d_start, d_incl, (size_t)n, rocprim::plus<uint32_t>(), stream));
+        }
+        uint32_t n_clusters = 0;
+        HIPC(hipMemcpy(&n_clusters, d_incl + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (n_clusters < 2 || n_clusters > n) return fail(TRT_EHIP, "trt_build_lbvh: internal error (cluster count)");
+        ClusterRec* d_rec = nullptr;
+        uint32_t *d_croot = nullptr, *d_cidx = nullptr, *d_cdepth = nullptr, *d_order2 = nullptr;
+        int32_t* d_shift = nullptr;
+        HIPC(mem.alloc(&d_rec, n_clusters));
+        HIPC(mem.alloc(&d_croot, n_clusters));
+        HIPC(mem.alloc(&d_cidx, n_clusters));
+        HIPC(mem.alloc(&d_cdepth, n_clusters));
+        HIPC(mem.alloc(&d_shift, n_clusters));
+        HIPC(mem.alloc(&d_order2, n));
+        hipLaunchKernelGGL(k_cluster_gather, dim3(grid_n), dim3(256), 0, stream, d_start, d_incl, d_root_at, d_first, d_last, d_pbox, d_order, d_nbox, n, d_rec, d_croot);
+        HIPC(hipGetLastError());
+        std::vector<ClusterRec> rec(n_clusters);
+        HIPC(hipMemcpy(rec.data(), d_rec, (size_t)n_clusters * sizeof(ClusterRec), hipMemcpyDeviceToHost));
+        uint64_t covered = 0;
+        for (const ClusterRec& r : rec) covered += r.count;
+        if (covered != n) return fail(TRT_EHIP, "trt_build_lbvh: internal error (clusters do not cover the triangles)");
+        TopBuilder top(rec);
+        float blo[3], bhi[3];
+        if (top.build(0, n_clusters, 0, blo, bhi) != 0) return fail(TRT_EHIP, "trt_build_lbvh: internal error (top tree)");
+        const uint32_t T = (uint32_t)top.nodes.size();
+        std::vector<int32_t> shift(n_clusters);
+        std::vector<uint32_t> new_first(n_clusters);
+        {
+            uint64_t at = 0;
+            for (uint32_t c : top.leaf_order) {
+                new_first[c] = (uint32_t)at;
+                shift[c] = (int32_t)((int64_t)at - (int64_t)rec[c].first);
+                at += rec[c].count;
+            }
+        }
+        HIPC(hipMemcpy(d_shift, shift.data(), (size_t)n_clusters * sizeof(int32_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_survive_in_clusters, dim3(grid_i), dim3(256), 0, stream, d_first, d_last, n_inner, (uint32_t)leaf_num, cluster, d_keep);
+        HIPC(hipGetLastError());
+        {
+            size_t tmp_bytes = 0;
+            HIPC(rocprim::exclusive_scan(nullptr, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+            char* d_tmp = nullptr;
+            HIPC(mem.alloc(&d_tmp, tmp_bytes));
+            HIPC(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+        }
+        uint32_t tail[2] = {0, 0};
+        HIPC(hipMemcpy(&tail[0], d_new + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(&tail[1], d_keep + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t n_in = tail[0] + tail[1];
+        if ((uint64_t)T + n_in > n_inner) return fail(TRT_EHIP, "trt_build_lbvh: internal error (node count)");
+        n_out = T + n_in;
+        if (n_out > node_capacity) return fail(TRT_EINVAL, "trt_build_lbvh: node_capacity too small (n_tris - 1 always suffices)");
+        trt_bvh_node* d_out = nullptr;
+        HIPC(mem.alloc(&d_out, n_in));
+        hipLaunchKernelGGL(k_emit_clusters, dim3(grid_i), dim3(256), 0, stream, d_pbox, d_order, d_nbox, d_left, d_right, d_first, d_last, d_keep, d_new, d_incl, d_shift, n_inner, T, d_out);
+        HIPC(hipGetLastError());
+        const uint32_t grid_c = (n_clusters + 255u) / 256u;
+        hipLaunchKernelGGL(k_cluster_root_index, dim3(grid_c), dim3(256), 0, stream, d_croot, d_keep, d_new, n_clusters, d_cidx);
+        HIPC(hipGetLastError());
+        hipLaunchKernelGGL(k_permute_order, dim3(grid_n), dim3(256), 0, stream, d_order, d_incl, d_shift, n, d_order2);
+        HIPC(hipGetLastError());
+        HIPC(hipMemsetAsync(d_cdepth, 0, (size_t)n_clusters * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_cluster_depth, dim3(grid_n), dim3(256), 0, stream, d_parent, d_leaf_parent, d_keep, d_incl, n, d_cdepth);
+        HIPC(hipGetLastError());
+        HIPC(hipEventRecord(ev1, stream));
+        std::vector<uint32_t> cidx(n_clusters), cdepth(n_clusters);
+        HIPC(hipMemcpy(cidx.data(), d_cidx, (size_t)n_clusters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(cdepth.data(), d_cdepth, (size_t)n_clusters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (n_in) HIPC(hipMemcpy(nodes_out + T, d_out, (size_t)n_in * sizeof(trt_bvh_node), hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(order_out, d_order2, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < T; ++k) {
+            const TopNode& t = top.nodes[k];
+            trt_bvh_node nd;
+            std::memset(&nd, 0, sizeof(nd));
+            for (int side = 0; side < 2; ++side) {
+                uint32_t ref;
+                if (t.child[side] >= 0) {
+                    ref = (uint32_t)t.child[side];
+                } else {
+                    const uint32_t c = (uint32_t)~t.child[side];
+                    ref = cidx[c] != 0xFFFFFFFFu ? T + cidx[c] : TRT_MAKE_LEAF(new_first[c], rec[c].count);
+                }
+                float* lo = side ? nd.lo1 : nd.lo0;
+                float* hi = side ? nd.hi1 : nd.hi0;
+                for (int a = 0; a < 3; ++a) { lo[a] = t.lo[side][a] - PAD; hi[a] = t.hi[side][a] + PAD; }
+                if (side) nd.child1 = ref; else nd.child0 = ref;
+            }
+            nodes_out[k] = nd;
+        }
+        for (uint32_t c = 0; c < n_clusters; ++c) depth = std::max(depth, top.top_depth[c] + cdepth[c]);
+    } else {
+        hipLaunchKernelGGL(k_survive, dim3(grid_i), dim3(256), 0, stream, d_first, d_last, n_inner, (uint32_t)leaf_num, d_keep);
+        HIPC(hipGetLastError());
+        {
+            size_t tmp_bytes = 0;
+            HIPC(rocprim::exclusive_scan(nullptr, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+            char* d_tmp = nullptr;
+            HIPC(mem.alloc(&d_tmp, tmp_bytes));
+            HIPC(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+        }
+        uint32_t tail[2] = {0, 0};
+        HIPC(hipMemcpy(&tail[0], d_new + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(&tail[1], d_keep + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        n_out = tail[0] + tail[1];
+        if (n_out < 1 || n_out > n_inner) return fail(TRT_EHIP, "trt_build_lbvh: internal error (node count)");
+        if (n_out > node_capacity) return fail(TRT_EINVAL, "trt_build_lbvh: node_capacity too small (n_tris - 1 always suffices)");
+        trt_bvh_node* d_out = nullptr;
+        HIPC(mem.alloc(&d_out, n_out));
+        hipLaunchKernelGGL(k_emit, dim3(grid_i), dim3(256), 0, stream, d_pbox, d_order, d_nbox, d_left, d_right, d_first, d_last, d_keep, d_new, n_inner, d_out);
+        HIPC(hipGetLastError());
+        HIPC(hipMemsetAsync(d_depth, 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_depth, dim3(grid_n), dim3(256), 0, stream, d_parent, d_leaf_parent, d_keep, n, d_depth);
+        HIPC(hipGetLastError());
+        HIPC(hipEventRecord(ev1, stream));
+        HIPC(hipMemcpy(nodes_out, d_out, (size_t)n_out * sizeof(trt_bvh_node), hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(order_out, d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(&depth, d_depth, sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
-    uint32_t tail[2] = {0, 0};
-    HIPC(hipMemcpy(&tail[0], d_new + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(&tail[1], d_keep + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
-    const uint32_t n_out = tail[0] + tail[1];
-    if (n_out < 1 || n_out > n_inner) return fail(TRT_EHIP, "trt_build_lbvh: internal error (node count)");
-    if (n_out > node_capacity) return fail(TRT_EINVAL, "trt_build_lbvh: node_capacity too small (n_tris - 1 always suffices)");
-    trt_bvh_node* d_out = nullptr;
-    HIPC(mem.alloc(&d_out, n_out));
-    hipLaunchKernelGGL(k_emit, dim3(grid_i), dim3(256), 0, stream, d_pbox, d_order, d_nbox, d_left, d_right, d_first, d_last, d_keep, d_new, n_inner, d_out);
-    HIPC(hipGetLastError());
-    HIPC(hipMemsetAsync(d_depth, 0, sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_depth, dim3(grid_n), dim3(256), 0, stream, d_parent, d_leaf_parent, d_keep, n, d_depth);
-    HIPC(hipGetLastError());
-    HIPC(hipEventRecord(ev1, stream));
-    HIPC(hipMemcpy(nodes_out, d_out, (size_t)n_out * sizeof(trt_bvh_node), hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(order_out, d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    uint32_t depth = 0;
-    HIPC(hipMemcpy(&depth, d_depth, sizeof(uint32_t), hipMemcpyDeviceToHost));
     *n_nodes_out = n_out;
     if (depth_out) *depth_out = depth;
     if (ms_out) {

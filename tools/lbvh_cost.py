@@ -26,8 +26,11 @@ def main():
     for spec in specs:
         name, n, w, h, spp = spec.split(":")
         n, w, h, spp = int(n), int(w), int(h), int(spp)
-        for builder in ("auto", "lbvh"):
-            s, t_build = scene(name, n, w, h, builder)
+        for builder in ("auto", "lbvh", "radix"):
+            if builder == "radix":
+                os.environ["TRT_LBVH_CLUSTER"] = "0"  # the radix tree as it is, no SAH top
+            s, t_build = scene(name, n, w, h, "lbvh" if builder == "radix" else builder)
+            os.environ.pop("TRT_LBVH_CLUSTER", None)
             f = s.flat.contents
             t = time.time()
             r = T.Renderer(s, 0)
@@ -38,7 +41,7 @@ def main():
             t = time.time()
             r.render(T.make_params(w, h, spp, 11))
             ms = (time.time() - t) * 1e3
-            extra = f" (device {s.build_ms[0]:.1f} ms, call {s.build_ms[1]:.0f} ms, rest = vertices out of / triangles reordered in the host scene)" if builder == "lbvh" else ""
+            extra = f" (device {s.build_ms[0]:.1f} ms, call {s.build_ms[1]:.0f} ms, rest = vertices out of / triangles reordered in the host scene)" if builder != "auto" else ""
             print(f"{name} {f.n_tris} triangles, {builder:5s}: build {t_build:.2f} s{extra}, {f.n_nodes} nodes depth {f.bvh_depth}, trt_create {t_create:.2f} s, "
                   f"visits/ray {(st.inner_visits[0] + st.inner_visits[1]) / rays:.2f} tests/ray {(st.tri_tests[0] + st.tri_tests[1]) / rays:.2f}, "
                   f"{w}x{h} {spp} spp: {ms:.1f} ms = {rays / ms / 1e3:.0f} Mrays/s", flush=True)
