@@ -14,8 +14,10 @@
 //                     64-B nodes of trt.h (a radix-tree node covers a contiguous range of the sorted order, so a subtree of
 //                     <= leaf_num triangles IS a leaf (first, count)); boxes padded like the reference's (bvh.cpp:31-40)
 //   K6 k_depth        inner nodes on the longest root path
-// All HBM-bound streaming or gather work, a few milliseconds for 10 M triangles; the call is dominated by moving the vertices
-// in (360 MB) and the nodes out (< 640 MB) over PCIe.  No MFMA, no LDS tiling: nothing here is a contraction.
+//   K7-K11 (default)  the top of the tree by SAH: the radix tree cut into clusters of <= 2048 triangles, an exact sweep-SAH tree over
+//                     the clusters built on the host, the cluster subtrees emitted below it (see "the top of the tree by SAH" below)
+// All HBM-bound streaming or gather work, some 40 ms for 10 M triangles (60 with the SAH top); the rest of the call is moving the
+// vertices in (360 MB) and the nodes out (< 640 MB) over PCIe.  No MFMA, no LDS tiling: nothing here is a contraction.
 #include <hip/hip_runtime.h>
 
 #include <string.h>
