@@ -55,8 +55,8 @@ $(OUT)/libtrt_lbvh.so: $(PKG)/csrc/trt_lbvh.hip include/trt.h include/trt_build.
 	@mkdir -p $(OUT)
 	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wextra -Wno-unused-parameter -Iinclude -shared -o $@ $(PKG)/csrc/trt_lbvh.hip
 
-$(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so
-	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -fopenmp -Wl,-rpath,'$$ORIGIN'
+$(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) include/trt_build.h $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so $(OUT)/libtrt_lbvh.so
+	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -ltrt_lbvh -fopenmp -Wl,-rpath,'$$ORIGIN'
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options

@@ -132,3 +132,23 @@ def test_config5_ten_million_triangles_built_on_the_device_tiles_vs_oracle():
     finally:
         r.close()
         s.close()
+
+
+def test_cli_gpu_bvh(tmp_path):
+    """tinyrt --gpu-bvh: the C++ host entry (trt::render with RenderOpts::gpu_builder) builds on the device, reorders scene.triangles by the
+    returned permutation and renders; the PNG has the bytes of the same render through the Python harness on the same device-built tree."""
+    import subprocess
+    exe = os.path.join(T.REPO_ROOT, "tinyraytracing_amd", "lib", "tinyrt")
+    d = os.path.join(T.SCENES_DIR, "staircase")
+    out = str(tmp_path / "cli.png")
+    r = subprocess.run([exe, d, os.path.join(d, "staircase.mtl"), os.path.join(d, "staircase.xml"), os.path.join(d, "staircase.obj"), "4", "--width", "96", "--height", "54",
+                        "--leaf", "2", "--gpu-bvh", "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    s = T.Scene.named("staircase", 96, 54, leaf_num=2, builder="lbvh")
+    rr = T.Renderer(s, 0)
+    img, _ = rr.render(T.make_params(96, 54, 4, 0x5EED0001))
+    ref = str(tmp_path / "py.png")
+    T.imshow(img, ref)
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    rr.close()
+    s.close()

@@ -47,10 +47,6 @@
 #pragma once
 #include "trt_path.h"
 
-#ifndef TRT_OCT_PK
-#define TRT_OCT_PK 0
-#endif
-
 namespace trtd {
 
 // Packed at a stride of 80 B: a node straddles two 128-B lines 3 times in 8.  One node per line (stride 128 B, measured:
@@ -126,27 +122,8 @@ TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, cons
         const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xFFu;                  // 0xFF in the bytes of inner children
         const uint32_t pos4 = (m4 ^ (R.octinv4 & inner_mask4)) & 0x1F1F1F1Fu;   // position in the hit mask
         const uint32_t bits4 = (m4 >> 5) & 0x07070707u;                         // what to set there: 1 (inner), unary count (leaf), 0 (empty)
-#if defined(__HIP_DEVICE_COMPILE__) && TRT_OCT_PK
-        // two children per v_pk_fma_f32 (5.1 clocks per wave against 2 x 4.2 for two v_fma_f32, tools/valu_probe.hip); the same IEEE
-        // fma per element, so the hit mask is the same
-        typedef float v2f __attribute__((ext_vector_type(2)));
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int k = 0; k < 4; k += 2) {
-            const v2f tnx = __builtin_elementwise_fma(v2f{octByte(nrx[h], k), octByte(nrx[h], k + 1)}, v2f{idx, idx}, v2f{onx, onx});
-            const v2f tny = __builtin_elementwise_fma(v2f{octByte(nry[h], k), octByte(nry[h], k + 1)}, v2f{idy, idy}, v2f{ony, ony});
-            const v2f tnz = __builtin_elementwise_fma(v2f{octByte(nrz[h], k), octByte(nrz[h], k + 1)}, v2f{idz, idz}, v2f{onz, onz});
-            const v2f tfx = __builtin_elementwise_fma(v2f{octByte(frx[h], k), octByte(frx[h], k + 1)}, v2f{idx, idx}, v2f{ofx, ofx});
-            const v2f tfy = __builtin_elementwise_fma(v2f{octByte(fry[h], k), octByte(fry[h], k + 1)}, v2f{idy, idy}, v2f{ofy, ofy});
-            const v2f tfz = __builtin_elementwise_fma(v2f{octByte(frz[h], k), octByte(frz[h], k + 1)}, v2f{idz, idz}, v2f{ofz, ofz});
-            const float tmin0 = fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, 0.0f)), tmax0 = fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, cull));
-            const float tmin1 = fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, 0.0f)), tmax1 = fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, cull));
-            const uint32_t b0 = (bits4 >> (8 * k)) & 0xFFu, p0 = (pos4 >> (8 * k)) & 0xFFu, b1 = (bits4 >> (8 * k + 8)) & 0xFFu, p1 = (pos4 >> (8 * k + 8)) & 0xFFu;
-            hits |= !(tmin0 > tmax0) ? (b0 << p0) : 0u;
-            hits |= !(tmin1 > tmax1) ? (b1 << p1) : 0u;
-        }
-#else
+        // (two children per v_pk_fma_f32 — 5.1 clocks per wave against 2 x 4.2, tools/valu_probe.hip — measured slower: the pairs have to
+        // be assembled first; profiles/r03_ab_oct.txt.  Removed.)
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -159,7 +136,6 @@ TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, cons
             const uint32_t b = (bits4 >> (8 * k)) & 0xFFu, p = (pos4 >> (8 * k)) & 0xFFu;
             hits |= hit ? (b << p) : 0u;
         }
-#endif
     }
     ng.x = f2u(q1.x);
     ng.y = (hits & 0xFF000000u) | (ew >> 24);

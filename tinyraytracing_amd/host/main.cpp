@@ -18,7 +18,7 @@ static void usage()
 {
     std::fprintf(stderr,
                  "usage: tinyrt <basedir> <mtl> <xml> <obj> <spp> [--width W --height H] [--seed S] [--device D | --gpus N | --devices a,b,..]\n"
-                 "              [--leaf N] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels] [--ray-offset] [--polygons]\n"
+                 "              [--leaf N] [--gpu-bvh] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels] [--ray-offset] [--polygons]\n"
                  "              [--every N] [--checkpoint file.acc] [--stop-after M]\n"
                  "                                                    progressive: N samples per step, image rewritten after\n"
                  "                                                    every step, accumulator kept in file.acc (resumes from it)\n");
@@ -60,6 +60,7 @@ int main(int argc, char** argv)
         }
         else if (!std::strcmp(argv[i], "--row-block")) opts.row_block = std::atoi(need("--row-block"));
         else if (!std::strcmp(argv[i], "--leaf")) opts.leaf_num = std::atoi(need("--leaf"));
+        else if (!std::strcmp(argv[i], "--gpu-bvh")) opts.gpu_builder = true;
         else if (!std::strcmp(argv[i], "--max-depth")) opts.max_depth = std::atoi(need("--max-depth"));
         else if (!std::strcmp(argv[i], "--out")) out_path = need("--out");
         else if (!std::strcmp(argv[i], "--fixed-nee")) opts.fixed_nee = true;

@@ -1,5 +1,7 @@
 #include "render.h"
 
+#include "trt_build.h"
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -74,7 +76,30 @@ void writeCheckpoint(const std::string& path, const Checkpoint& head, const std:
 
 void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stats)
 {
-    FlatBVH bvh = buildBVH(scene.triangles, opts.leaf_num, opts.builder);
+    FlatBVH bvh;
+    if (opts.gpu_builder) {
+        // buildBVH on the device (main.cpp:76): the nodes, and the permutation that is the reference's in-place sort of scene.triangles
+        const size_t n = scene.triangles.size();
+        std::vector<float> v(std::max<size_t>(n, 1) * 9);
+        for (size_t i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) {
+                v[i * 9 + k * 3 + 0] = scene.triangles[i].v[k].x;
+                v[i * 9 + k * 3 + 1] = scene.triangles[i].v[k].y;
+                v[i * 9 + k * 3 + 2] = scene.triangles[i].v[k].z;
+            }
+        bvh.nodes.resize(std::max<size_t>(n, 2) - 1);
+        std::vector<uint32_t> order(std::max<size_t>(n, 1));
+        uint32_t n_nodes = 0;
+        const int dev = opts.devices.empty() ? opts.device : opts.devices[0];
+        if (trt_build_lbvh(v.data(), (uint32_t)n, opts.leaf_num, dev, bvh.nodes.data(), (uint32_t)bvh.nodes.size(), &n_nodes, order.data(), &bvh.depth, nullptr) != TRT_OK)
+            throw std::runtime_error(std::string("trt_build_lbvh: ") + trt_build_last_error());
+        bvh.nodes.resize(n_nodes);
+        std::vector<Triangle> sorted(n);
+        for (size_t i = 0; i < n; ++i) sorted[i] = std::move(scene.triangles[order[i]]);
+        scene.triangles.swap(sorted);
+    } else {
+        bvh = buildBVH(scene.triangles, opts.leaf_num, opts.builder);
+    }
     FlatScene flat;
     flat.build(scene, bvh);
 

@@ -21,6 +21,7 @@ struct RenderOpts {
     int row_block = 8;        // stripe height of that tiling
     int leaf_num = 2;         // the reference calls buildBVH(..., 8) (main.cpp:76); 2 is fastest on the GPU
     BvhBuilder builder = BVH_AUTO;
+    bool gpu_builder = false;  // build the BVH on the GPU instead (trt_build_lbvh, include/trt_build.h: LBVH with a SAH top; `builder` is then ignored)
     int max_depth = 0;
     uint64_t mem_budget = 0;
     bool timing = false;

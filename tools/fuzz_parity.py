@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak: random tiles / row interleaves / spp / seeds / flags / depth caps / memory budgets of the three cg22
-scenes (and a 50 k-triangle soup) rendered by the HIP path through the C-ABI — default handles and handles on the optional code paths
+scenes (and a 50 k-triangle soup) rendered by the HIP path through the C-ABI — default handles, handles on trees of the GPU builder, and handles on the optional code paths
 (quantised nodes, speculative scheduler, per-lane traversal of the tiny scene) — and by the oracle; every image and every ray count
 must be identical.  usage: tools/fuzz_parity.py [seconds] [seed]"""
 import os
@@ -20,10 +20,13 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sizes = {"back": (257, 131), "veach-mis": (320, 180), "staircase": (192, 108), "soup": (160, 90)}
-    scenes, renderers, alt = {}, {}, {}
+    scenes, renderers, alt, scenes_gpu_tree, on_gpu_tree = {}, {}, {}, {}, {}
     for name, (w, h) in sizes.items():
         scenes[name] = T.Scene.named(name, w, h, **({"n": 50000} if name == "soup" else {}))
         renderers[name] = T.Renderer(scenes[name], 0)
+        # a third handle per scene on the tree of the GPU builder (include/trt_build.h): the oracle walks that tree for it
+        scenes_gpu_tree[name] = T.Scene.named(name, w, h, builder="lbvh", **({"n": 50000} if name == "soup" else {}))
+        on_gpu_tree[name] = T.Renderer(scenes_gpu_tree[name], 0)
         # a second handle per scene on the OTHER node kind of the traversal kernels (exact 4-wide nodes where the default is the 8-wide
         # compressed ones), and per-lane traversal instead of the uniform walk for the tiny scene
         os.environ["TRT_NODE_KIND"] = "0"
@@ -58,13 +61,15 @@ def main():
         p = T.make_params(w, h, spp, seed, tile=(x0, y0, x1, y1), rows=rows, max_depth=md, flags=flags, mem_budget=budget_b)
         if not T.rows_selected(p):
             continue
+        pick = rng.random()
+        use = on_gpu_tree if pick < 0.25 else (alt if pick < 0.55 else renderers)
         try:
-            img, st = (alt if rng.random() < 0.4 else renderers)[name].render(p)
+            img, st = use[name].render(p)
         except T.TrtError as e:
             if "mem_budget too small" in str(e):
                 continue
             raise
-        ref, ost = O.render(scenes[name].flat, p)
+        ref, ost = O.render((scenes_gpu_tree if use is on_gpu_tree else scenes)[name].flat, p)
         ok = np.array_equal(img, ref) and (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
         n += 1
         if not ok:
