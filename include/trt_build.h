@@ -8,7 +8,7 @@
  * permutation that puts the caller's triangles into leaf order.  The tree is an LBVH (Lauterbach et al. 2009; hierarchy of
  * Karras 2012): 63-bit Morton codes of the centres of the triangles' boxes, one radix sort, every inner node from its
  * own index, boxes bottom-up.  Its top is SAH: the radix tree is cut into its maximal subtrees of <= 2048 triangles
- * (TRT_LBVH_CLUSTER in the environment; 0 = keep the radix tree as it is), an exact sweep-SAH tree over those clusters — a few
+ * (n / 64 for scenes below 131 k triangles, at least 256; TRT_LBVH_CLUSTER in the environment overrides; 0 = keep the radix tree as it is), an exact sweep-SAH tree over those clusters — a few
  * thousand boxes, built on the host in milliseconds — becomes the upper part of the BVH, and each cluster's radix subtree
  * hangs below its leaf (node visits per ray within 4-7 % of the host SAH builder's tree on scenes of 1-10 M triangles, against
  * 4-23 % for the radix tree alone).  Topology is free
