@@ -1368,7 +1368,8 @@ int trt_group_render_device(trt_group* g, const trt_params* p_in, float* out_dev
         if (rc == 0) {
             for (int k = 0; k < n && rc == 0 && herr == hipSuccess; ++k) {
                 herr = hipSetDevice(g->devices[k]);
-                if (herr == hipSuccess) rc = g->rccl.Gather(g->stripe[k].p, k == 0 ? g->gathered.p : nullptr, count, NCCL_FLOAT32, 0, g->comms[k], g->streams[k]);
+                // (a rank that is not the root receives nothing; it still gets a valid pointer — its own stripe — in case a build of the library checks the argument)
+                if (herr == hipSuccess) rc = g->rccl.Gather(g->stripe[k].p, k == 0 ? g->gathered.p : g->stripe[k].p, count, NCCL_FLOAT32, 0, g->comms[k], g->streams[k]);
             }
             const int rc_end = g->rccl.GroupEnd();
             if (rc == 0) rc = rc_end;
