@@ -207,38 +207,69 @@ __device__ inline void loadBoxCoherent(const Box8* p, float out[6])
     out[5] = __hip_atomic_load(f + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// K4: nbox[i] = bounds of inner node i.  arrivals[] starts at 0.
-__global__ __launch_bounds__(256) void k_boxes_up(const Box8* __restrict__ pbox, const uint32_t* __restrict__ order, uint32_t n_prims, const uint32_t* __restrict__ left,
-                                                  const uint32_t* __restrict__ right, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent,
-                                                  Box8* nbox, uint32_t* arrivals)
+// K4: nbox[i] = bounds of inner node i.  arrivals[] (global) starts at 0.
+// One thread per triangle climbs from its leaf carrying the box of the subtree it has completed; at a node the first of the two
+// threads to arrive is done, the second merges the SIBLING's box into its own, stores the node's box and goes on.  A block owns the 1024
+// consecutive sorted positions of its threads.  A radix-tree node's index is one end of its range, so a node whose whole range lies
+// inside the block's positions — all but about ten of the block's 1023 — has a slot in LDS: arrival counter and box live there (LDS
+// atomics, a workgroup fence), and only its final box is written to memory.  The nodes that span a block boundary meet at AGENT scope
+// in memory, which on this chip (eight XCDs, an L2 each) means write-back and invalidation of an L2 per arrival: with every node
+// handled that way this kernel took 36 of the builder's 40 ms for 10 M triangles; with only the ~300 k boundary arrivals at agent scope
+// it takes 11.5 ms (profiles/r03_lbvh_kernel_stats.csv) — still the largest kernel of the build: what is left is those fences (the same
+// time with the local nodes synchronised through memory at workgroup scope instead of LDS).  Next step, not taken: stop at the block
+// boundary and finish the few thousand spanning nodes in per-level launches, whose kernel boundaries give the coherence for free.
+// The thread that completes a node is the one that goes on to its parent, so the release it performs there covers the box it has
+// just stored, whatever the levels below used.
+constexpr uint32_t BOXES_UP_BLOCK = 1024;
+__global__ __launch_bounds__(BOXES_UP_BLOCK) void k_boxes_up(const Box8* __restrict__ pbox, const uint32_t* __restrict__ order, uint32_t n_prims, const uint32_t* __restrict__ left,
+                                                             const uint32_t* __restrict__ right, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                             const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent, Box8* nbox, uint32_t* arrivals)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_box[6][BOXES_UP_BLOCK];
+    __shared__ uint32_t s_arrivals[BOXES_UP_BLOCK];
+    const uint32_t own_lo = blockIdx.x * BOXES_UP_BLOCK, own_hi = own_lo + BOXES_UP_BLOCK - 1u;
+    const uint32_t p = own_lo + threadIdx.x;
+    s_arrivals[threadIdx.x] = 0u;
+    __syncthreads();  // (the only barrier: threads leave the kernel one by one after it)
     if (p >= n_prims || n_prims < 2) return;
-    uint32_t node = leaf_parent[p];
+    float cur[6];
+    {
+        const Box8 x = pbox[order[p]];
+        cur[0] = x.a.x; cur[1] = x.a.y; cur[2] = x.a.z; cur[3] = x.a.w; cur[4] = x.b.x; cur[5] = x.b.y;
+    }
+    uint32_t came_from = LEAF | p, node = leaf_parent[p];
+    auto isLocal = [&](uint32_t i) { return first[i] >= own_lo && last[i] <= own_hi; };
     for (uint32_t guard = 0; guard < 4096u; ++guard) {  // (a root path is at most 63 + 32 nodes long; the guard only bounds a corrupted tree)
-        // the second thread to arrive finds both children complete; the first one is done
-        if (__hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-        const uint32_t ch[2] = {left[node], right[node]};
-        for (int k = 0; k < 2; ++k) {
-            float b[6];
-            if (ch[k] & LEAF) {
-                const Box8 x = pbox[order[ch[k] & ~LEAF]];
-                b[0] = x.a.x; b[1] = x.a.y; b[2] = x.a.z; b[3] = x.a.w; b[4] = x.b.x; b[5] = x.b.y;
-            } else {
-                loadBoxCoherent(nbox + ch[k], b);
-            }
-            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], b[a]); hi[a] = fmaxf(hi[a], b[3 + a]); }
+        const bool local = isLocal(node);
+        uint32_t before;
+        if (local) {
+            __threadfence_block();  // my subtree's box (s_box, if it is a node's) before my arrival
+            before = atomicAdd(&s_arrivals[node - own_lo], 1u);
+            __threadfence_block();
+        } else {
+            before = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         }
-        float* o = reinterpret_cast<float*>(nbox + node);
-        __hip_atomic_store(o + 0, lo[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o + 1, lo[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o + 2, lo[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o + 3, hi[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o + 4, hi[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o + 5, hi[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == 0u) return;  // the other child is still under way: its thread will finish this node
+        const uint32_t l = left[node], r = right[node], sib = (l == came_from) ? r : l;
+        float b[6];
+        if (sib & LEAF) {
+            const Box8 x = pbox[order[sib & ~LEAF]];
+            b[0] = x.a.x; b[1] = x.a.y; b[2] = x.a.z; b[3] = x.a.w; b[4] = x.b.x; b[5] = x.b.y;
+        } else if (local) {  // both children of a local node are local
+            for (int k = 0; k < 6; ++k) b[k] = s_box[k][sib - own_lo];
+        } else {
+            loadBoxCoherent(nbox + sib, b);
+        }
+        for (int a = 0; a < 3; ++a) { cur[a] = fminf(cur[a], b[a]); cur[3 + a] = fmaxf(cur[3 + a], b[3 + a]); }
+        if (local)
+            for (int k = 0; k < 6; ++k) s_box[k][node - own_lo] = cur[k];
+        Box8 out;
+        out.a = make_float4(cur[0], cur[1], cur[2], cur[3]);
+        out.b = make_float4(cur[4], cur[5], 0.0f, 0.0f);
+        nbox[node] = out;  // for the kernels behind this one, and for the thread of another block that merges at an ancestor (my release there covers it)
         const uint32_t up = parent[node];
         if (up == 0xFFFFFFFFu) return;  // the root
+        came_from = node;
         node = up;
     }
 }
@@ -409,10 +440,11 @@ __global__ __launch_bounds__(256) void k_cluster_depth(const uint32_t* __restric
     if (p >= n_prims) return;
     uint32_t d = 0, node = leaf_parent[p];
     for (uint32_t guard = 0; guard < 4096u && node != 0xFFFFFFFFu; ++guard) {  // (`keep` is 0 below the leaves' roots and above the cluster's root)
-        d += keep[node];
+        if (keep[node]) ++d;
+        else if (d) break;  // past the cluster's root
         node = parent[node];
     }
-    if (d) atomicMax(&cdepth[incl[p] - 1u], d);
+    if (d && d > cdepth[incl[p] - 1u]) atomicMax(&cdepth[incl[p] - 1u], d);  // (the plain read only saves atomics: thousands of triangles share a cluster's word)
 }
 
 // ---- host: exact sweep SAH over the clusters, cost = half-area x triangles
@@ -613,7 +645,7 @@ int trt_build_lbvh(const float* tri_v, uint32_t n_tris, int leaf_num, int device
     hipLaunchKernelGGL(k_hierarchy, dim3(grid_i), dim3(256), 0, stream, d_keys2, n, d_left, d_right, d_first, d_last, d_parent, d_leaf_parent);
     HIPC(hipGetLastError());
     HIPC(hipMemsetAsync(d_arrivals, 0, (size_t)n_inner * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_boxes_up, dim3(grid_n), dim3(256), 0, stream, d_pbox, d_order, n, d_left, d_right, d_parent, d_leaf_parent, d_nbox, d_arrivals);
+    hipLaunchKernelGGL(k_boxes_up, dim3((n + BOXES_UP_BLOCK - 1u) / BOXES_UP_BLOCK), dim3(BOXES_UP_BLOCK), 0, stream, d_pbox, d_order, n, d_left, d_right, d_first, d_last, d_parent, d_leaf_parent, d_nbox, d_arrivals);
     HIPC(hipGetLastError());
     // ---- the top of the tree by SAH over clusters of the radix tree (TRT_LBVH_CLUSTER triangles at most; 0: the radix tree as it is)
     // largest cluster: 2048 triangles for the big scenes (measured: 512 and 8192 are behind on 1-10 M triangles), n / 64 for smaller ones so that
