@@ -8,15 +8,15 @@
 //   K3 k_hierarchy    inner node i of the radix tree over the sorted codes from i alone (Karras 2012: direction, range by
 //                     doubling + bisection on the common-prefix length, split by bisection; equal codes are told apart by
 //                     their position, so runs of duplicates become balanced subtrees)
-//   K4 k_boxes_up     boxes bottom-up: one thread per triangle climbs, the second arrival at a node (acquire/release counter)
-//                     merges its children and goes on; every thread ends at a node it reaches first or at the root
+//   K4 k_boxes_up + k_span_round   boxes bottom-up: one thread per triangle climbs, the second arrival at a node merges and goes on —
+//                     inside a block's 1024 positions in LDS; the few nodes that span blocks in per-level launches behind it
 //   K5 k_survive + rocprim::exclusive_scan + k_emit   inner nodes that hold more than leaf_num triangles become the flat
 //                     64-B nodes of trt.h (a radix-tree node covers a contiguous range of the sorted order, so a subtree of
 //                     <= leaf_num triangles IS a leaf (first, count)); boxes padded like the reference's (bvh.cpp:31-40)
 //   K6 k_depth        inner nodes on the longest root path
 //   K7-K11 (default)  the top of the tree by SAH: the radix tree cut into clusters of <= 2048 triangles, an exact sweep-SAH tree over
 //                     the clusters built on the host, the cluster subtrees emitted below it (see "the top of the tree by SAH" below)
-// All HBM-bound streaming or gather work, some 40 ms for 10 M triangles (60 with the SAH top); the rest of the call is moving the
+// All HBM-bound streaming or gather work, 5.5 ms of kernels for 10 M triangles (23 ms with the host's SAH over the clusters in between); the rest of the call is moving the
 // vertices in (360 MB) and the nodes out (< 640 MB) over PCIe.  No MFMA, no LDS tiling: nothing here is a contraction.
 #include <hip/hip_runtime.h>
 
@@ -195,39 +195,27 @@ __global__ __launch_bounds__(256) void k_hierarchy(const unsigned long long* __r
     if (i == 0) parent[0] = 0xFFFFFFFFu;
 }
 
-__device__ inline void loadBoxCoherent(const Box8* p, float out[6])
-{
-    // written by another thread of this launch: read past the L1 (the acquire of the counter orders it)
-    const float* f = reinterpret_cast<const float*>(p);
-    out[0] = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[1] = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[2] = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[3] = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[4] = __hip_atomic_load(f + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[5] = __hip_atomic_load(f + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// K4: nbox[i] = bounds of inner node i.  arrivals[] (global) starts at 0.
-// One thread per triangle climbs from its leaf carrying the box of the subtree it has completed; at a node the first of the two
+// K4: nbox[i] = bounds of inner node i, in two parts.
+// K4a: one thread per triangle climbs from its leaf carrying the box of the subtree it has completed; at a node the first of the two
 // threads to arrive is done, the second merges the SIBLING's box into its own, stores the node's box and goes on.  A block owns the 1024
 // consecutive sorted positions of its threads.  A radix-tree node's index is one end of its range, so a node whose whole range lies
 // inside the block's positions — all but about ten of the block's 1023 — has a slot in LDS: arrival counter and box live there (LDS
-// atomics, a workgroup fence), and only its final box is written to memory.  The nodes that span a block boundary meet at AGENT scope
-// in memory, which on this chip (eight XCDs, an L2 each) means write-back and invalidation of an L2 per arrival: with every node
-// handled that way this kernel took 36 of the builder's 40 ms for 10 M triangles; with only the ~300 k boundary arrivals at agent scope
-// it takes 11.5 ms (profiles/r03_lbvh_kernel_stats.csv) — still the largest kernel of the build: what is left is those fences (the same
-// time with the local nodes synchronised through memory at workgroup scope instead of LDS).  Next step, not taken: stop at the block
-// boundary and finish the few thousand spanning nodes in per-level launches, whose kernel boundaries give the coherence for free.
-// The thread that completes a node is the one that goes on to its parent, so the release it performs there covers the box it has
-// just stored, whatever the levels below used.
+// atomics, a workgroup fence), its final box goes to memory.  The climb ENDS at the first node that spans a block boundary: meeting
+// another block's thread there would take agent-scope acquire/release, which on this chip (eight XCDs, an L2 each) is a write-back and
+// an invalidation of an L2 per arrival — with every node handled that way the kernel took 36 of the builder's 40 ms for 10 M triangles,
+// with only the spanning nodes 11.5 ms.
+// K4b: the spanning nodes (about ten per block, compacted into a list) are finished level by level: one small launch per round computes
+// every listed node whose two children are complete; the kernel boundary is all the coherence the rounds need.
 constexpr uint32_t BOXES_UP_BLOCK = 1024;
+__device__ inline bool spansBlocks(uint32_t first, uint32_t last) { return first / BOXES_UP_BLOCK != last / BOXES_UP_BLOCK; }
+
 __global__ __launch_bounds__(BOXES_UP_BLOCK) void k_boxes_up(const Box8* __restrict__ pbox, const uint32_t* __restrict__ order, uint32_t n_prims, const uint32_t* __restrict__ left,
                                                              const uint32_t* __restrict__ right, const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-                                                             const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent, Box8* nbox, uint32_t* arrivals)
+                                                             const uint32_t* __restrict__ parent, const uint32_t* __restrict__ leaf_parent, Box8* __restrict__ nbox)
 {
     __shared__ float s_box[6][BOXES_UP_BLOCK];
     __shared__ uint32_t s_arrivals[BOXES_UP_BLOCK];
-    const uint32_t own_lo = blockIdx.x * BOXES_UP_BLOCK, own_hi = own_lo + BOXES_UP_BLOCK - 1u;
+    const uint32_t own_lo = blockIdx.x * BOXES_UP_BLOCK;
     const uint32_t p = own_lo + threadIdx.x;
     s_arrivals[threadIdx.x] = 0u;
     __syncthreads();  // (the only barrier: threads leave the kernel one by one after it)
@@ -238,40 +226,70 @@ __global__ __launch_bounds__(BOXES_UP_BLOCK) void k_boxes_up(const Box8* __restr
         cur[0] = x.a.x; cur[1] = x.a.y; cur[2] = x.a.z; cur[3] = x.a.w; cur[4] = x.b.x; cur[5] = x.b.y;
     }
     uint32_t came_from = LEAF | p, node = leaf_parent[p];
-    auto isLocal = [&](uint32_t i) { return first[i] >= own_lo && last[i] <= own_hi; };
     for (uint32_t guard = 0; guard < 4096u; ++guard) {  // (a root path is at most 63 + 32 nodes long; the guard only bounds a corrupted tree)
-        const bool local = isLocal(node);
-        uint32_t before;
-        if (local) {
-            __threadfence_block();  // my subtree's box (s_box, if it is a node's) before my arrival
-            before = atomicAdd(&s_arrivals[node - own_lo], 1u);
-            __threadfence_block();
-        } else {
-            before = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (spansBlocks(first[node], last[node])) return;  // K4b's
+        __threadfence_block();  // my subtree's box (s_box, if it is a node's) before my arrival
+        const uint32_t before = atomicAdd(&s_arrivals[node - own_lo], 1u);
+        __threadfence_block();
         if (before == 0u) return;  // the other child is still under way: its thread will finish this node
         const uint32_t l = left[node], r = right[node], sib = (l == came_from) ? r : l;
         float b[6];
         if (sib & LEAF) {
             const Box8 x = pbox[order[sib & ~LEAF]];
             b[0] = x.a.x; b[1] = x.a.y; b[2] = x.a.z; b[3] = x.a.w; b[4] = x.b.x; b[5] = x.b.y;
-        } else if (local) {  // both children of a local node are local
+        } else {  // both children of a node inside the block are inside it
             for (int k = 0; k < 6; ++k) b[k] = s_box[k][sib - own_lo];
-        } else {
-            loadBoxCoherent(nbox + sib, b);
         }
         for (int a = 0; a < 3; ++a) { cur[a] = fminf(cur[a], b[a]); cur[3 + a] = fmaxf(cur[3 + a], b[3 + a]); }
-        if (local)
-            for (int k = 0; k < 6; ++k) s_box[k][node - own_lo] = cur[k];
+        for (int k = 0; k < 6; ++k) s_box[k][node - own_lo] = cur[k];
         Box8 out;
         out.a = make_float4(cur[0], cur[1], cur[2], cur[3]);
         out.b = make_float4(cur[4], cur[5], 0.0f, 0.0f);
-        nbox[node] = out;  // for the kernels behind this one, and for the thread of another block that merges at an ancestor (my release there covers it)
+        nbox[node] = out;
         const uint32_t up = parent[node];
-        if (up == 0xFFFFFFFFu) return;  // the root
+        if (up == 0xFFFFFFFFu) return;  // the root (a scene of one block)
         came_from = node;
         node = up;
     }
+}
+
+// K4b, list: flag = 1 for the nodes that span blocks; `pos` = exclusive scan of the flags
+__global__ __launch_bounds__(256) void k_span_flags(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, uint32_t n_inner, uint32_t* __restrict__ flag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_inner) flag[i] = spansBlocks(first[i], last[i]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_span_list(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n_inner, uint32_t* __restrict__ list)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_inner && flag[i]) list[pos[i]] = i;
+}
+// K4b, one round: a child is complete if it is a triangle, a node K4a finished (it does not span), or marked done by an EARLIER launch (done_in: read
+// only; this launch marks in done_out, and the two swap between rounds).  `remaining` counts the listed nodes that had to wait.
+__global__ __launch_bounds__(256) void k_span_round(const uint32_t* __restrict__ list, uint32_t m, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                    const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, const Box8* __restrict__ pbox,
+                                                    const uint32_t* __restrict__ order, Box8* nbox, const uint32_t* done_in, uint32_t* done_out, uint32_t* __restrict__ remaining)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const uint32_t node = list[t];
+    if (done_in[node]) { done_out[node] = 1u; return; }
+    const uint32_t ch[2] = {left[node], right[node]};
+    bool ready = true;
+    for (int k = 0; k < 2; ++k)
+        if (!(ch[k] & LEAF) && spansBlocks(first[ch[k]], last[ch[k]]) && !done_in[ch[k]]) ready = false;
+    if (!ready) { atomicAdd(remaining, 1u); return; }
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int k = 0; k < 2; ++k) {
+        const Box8 x = (ch[k] & LEAF) ? pbox[order[ch[k] & ~LEAF]] : nbox[ch[k]];
+        lo[0] = fminf(lo[0], x.a.x); lo[1] = fminf(lo[1], x.a.y); lo[2] = fminf(lo[2], x.a.z);
+        hi[0] = fmaxf(hi[0], x.a.w); hi[1] = fmaxf(hi[1], x.b.x); hi[2] = fmaxf(hi[2], x.b.y);
+    }
+    Box8 out;
+    out.a = make_float4(lo[0], lo[1], lo[2], hi[0]);
+    out.b = make_float4(hi[1], hi[2], 0.0f, 0.0f);
+    nbox[node] = out;
+    done_out[node] = 1u;
 }
 
 // K5a: 1 for the inner nodes that stay nodes (more than leaf_num triangles below them)
@@ -644,9 +662,48 @@ int trt_build_lbvh(const float* tri_v, uint32_t n_tris, int leaf_num, int device
     const uint32_t grid_i = (n_inner + 255u) / 256u;
     hipLaunchKernelGGL(k_hierarchy, dim3(grid_i), dim3(256), 0, stream, d_keys2, n, d_left, d_right, d_first, d_last, d_parent, d_leaf_parent);
     HIPC(hipGetLastError());
-    HIPC(hipMemsetAsync(d_arrivals, 0, (size_t)n_inner * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_boxes_up, dim3((n + BOXES_UP_BLOCK - 1u) / BOXES_UP_BLOCK), dim3(BOXES_UP_BLOCK), 0, stream, d_pbox, d_order, n, d_left, d_right, d_first, d_last, d_parent, d_leaf_parent, d_nbox, d_arrivals);
+    hipLaunchKernelGGL(k_boxes_up, dim3((n + BOXES_UP_BLOCK - 1u) / BOXES_UP_BLOCK), dim3(BOXES_UP_BLOCK), 0, stream, d_pbox, d_order, n, d_left, d_right, d_first, d_last, d_parent, d_leaf_parent, d_nbox);
     HIPC(hipGetLastError());
+    if (n > BOXES_UP_BLOCK) {  // K4b: the nodes that span blocks, level by level (d_keep / d_new / d_arrivals serve as flag / position / done here)
+        uint32_t* d_done2 = nullptr;
+        uint32_t* d_list = nullptr;
+        HIPC(mem.alloc(&d_done2, n_inner));
+        hipLaunchKernelGGL(k_span_flags, dim3(grid_i), dim3(256), 0, stream, d_first, d_last, n_inner, d_keep);
+        HIPC(hipGetLastError());
+        {
+            size_t tmp_bytes = 0;
+            HIPC(rocprim::exclusive_scan(nullptr, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+            char* d_tmp = nullptr;
+            HIPC(mem.alloc(&d_tmp, tmp_bytes));
+            HIPC(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_keep, d_new, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
+        }
+        uint32_t tail[2] = {0, 0};
+        HIPC(hipMemcpy(&tail[0], d_new + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(&tail[1], d_keep + (n_inner - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t m = tail[0] + tail[1];
+        if (m) {
+            HIPC(mem.alloc(&d_list, m));
+            hipLaunchKernelGGL(k_span_list, dim3(grid_i), dim3(256), 0, stream, d_keep, d_new, n_inner, d_list);
+            HIPC(hipGetLastError());
+            HIPC(hipMemsetAsync(d_arrivals, 0, (size_t)n_inner * sizeof(uint32_t), stream));
+            HIPC(hipMemsetAsync(d_done2, 0, (size_t)n_inner * sizeof(uint32_t), stream));
+            uint32_t* done_in = d_arrivals;
+            uint32_t* done_out = d_done2;
+            uint32_t remaining = m;
+            for (uint32_t round = 0; remaining != 0u; ++round) {
+                if (round >= 160u) return fail(TRT_EHIP, "trt_build_lbvh: internal error (the spanning nodes do not finish)");
+                // eight rounds between two looks at the counter (a tree of 10 M triangles needs about 25)
+                for (int k = 0; k < 8; ++k) {
+                    HIPC(hipMemsetAsync(d_depth, 0, sizeof(uint32_t), stream));
+                    hipLaunchKernelGGL(k_span_round, dim3((m + 255u) / 256u), dim3(256), 0, stream, d_list, m, d_left, d_right, d_first, d_last, d_pbox, d_order, d_nbox, done_in, done_out, d_depth);
+                    HIPC(hipGetLastError());
+                    std::swap(done_in, done_out);
+                }
+                round += 7u;
+                HIPC(hipMemcpy(&remaining, d_depth, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
+        }
+    }
     // ---- the top of the tree by SAH over clusters of the radix tree (TRT_LBVH_CLUSTER triangles at most; 0: the radix tree as it is)
     // largest cluster: 2048 triangles for the big scenes (measured: 512 and 8192 are behind on 1-10 M triangles), n / 64 for smaller ones so that
     // the SAH top has a few dozen leaves to work with (staircase, 31 k triangles: 512 is 2 % ahead of 2048), never below 256
