@@ -167,3 +167,35 @@ def test_validation_on_several_host_threads_finds_faults_deep_in_a_big_tree(monk
                 needles = needle if isinstance(needle, tuple) else (needle,)
                 assert rc == 1 and any(x in lib.trt_last_error() for x in needles), (threads, what, rc, lib.trt_last_error())
     s.close()
+
+
+def test_adopting_a_foreign_tree_reorders_the_triangles_like_the_in_place_sort():
+    """trth_scene_vertices / trth_scene_adopt_bvh (the host side of the GPU builder's hand-over): adopting the host builder's own nodes with the
+    identity order leaves the flat scene as it was; a reversed two-leaf tree with the reversed order reverses the triangle arrays; an order that is
+    not a permutation is refused."""
+    import numpy as np
+    import tinyraytracing_amd as T
+    from tinyraytracing_amd._abi import BvhNode
+    host = _abi.load_host()
+    s = T.Scene.named("veach-mis", 32, 18)
+    f = s.flat.contents
+    n, nn = f.n_tris, f.n_nodes
+    v0 = np.ctypeslib.as_array(f.tri_v, shape=(n * 9,)).copy()
+    mat0 = np.ctypeslib.as_array(f.tri_mat, shape=(n,)).copy()
+    nodes = (BvhNode * nn)()
+    C.memmove(nodes, f.nodes, C.sizeof(BvhNode) * nn)
+    v = np.empty(n * 9, np.float32)
+    assert host.trth_scene_vertices(s._h, v.ctypes.data_as(C.POINTER(C.c_float)), v.size) == 0 and np.array_equal(v, v0)
+    ident = np.arange(n, dtype=np.uint32)
+    assert host.trth_scene_adopt_bvh(s._h, nodes, nn, ident.ctypes.data_as(C.POINTER(C.c_uint32)), f.bvh_depth) == 0
+    f = s.flat.contents
+    assert np.array_equal(np.ctypeslib.as_array(f.tri_v, shape=(n * 9,)), v0) and f.n_nodes == nn
+    rev = ident[::-1].copy()
+    assert host.trth_scene_adopt_bvh(s._h, nodes, nn, rev.ctypes.data_as(C.POINTER(C.c_uint32)), f.bvh_depth) == 0
+    f = s.flat.contents
+    assert np.array_equal(np.ctypeslib.as_array(f.tri_v, shape=(n, 9)), v0.reshape(n, 9)[::-1])
+    assert np.array_equal(np.ctypeslib.as_array(f.tri_mat, shape=(n,)), mat0[::-1])
+    bad = ident.copy()
+    bad[3] = bad[4]
+    assert host.trth_scene_adopt_bvh(s._h, nodes, nn, bad.ctypes.data_as(C.POINTER(C.c_uint32)), 1) == 1 and b"permutation" in host.trth_last_error()
+    s.close()
