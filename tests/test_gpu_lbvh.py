@@ -152,3 +152,31 @@ def test_cli_gpu_bvh(tmp_path):
     assert open(out, "rb").read() == open(ref, "rb").read()
     rr.close()
     s.close()
+
+
+def test_builder_refuses_what_it_cannot_return():
+    """A node array that is too small is an error with a message, not an overrun; the reported depth is what trt_create measures on the tree."""
+    from tinyraytracing_amd import _abi
+    b = _abi.load_build()
+    rng = np.random.default_rng(2)
+    n = 5000
+    v = (rng.random((n, 3, 3), dtype=np.float32) * 0.05 + rng.random((n, 1, 3), dtype=np.float32)).astype(np.float32).reshape(-1)
+    order = np.empty(n, np.uint32)
+    nn, depth = C.c_uint32(0), C.c_uint32(0)
+    small = (_abi.BvhNode * 16)()
+    rc = b.trt_build_lbvh(v.ctypes.data_as(C.POINTER(C.c_float)), n, 2, 0, small, 16, C.byref(nn), order.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(depth), None)
+    assert rc == 1 and b"node_capacity" in b.trt_build_last_error()
+    nodes = (_abi.BvhNode * (n - 1))()
+    ms = (C.c_double * 2)()
+    rc = b.trt_build_lbvh(v.ctypes.data_as(C.POINTER(C.c_float)), n, 2, 0, nodes, n - 1, C.byref(nn), order.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(depth), ms)
+    assert rc == 0 and 0 < nn.value <= n - 1 and sorted(order.tolist()) == list(range(n)) and ms[1] >= ms[0] > 0
+    # the depth it reports = the longest chain of inner nodes from the root
+    kids = {}
+    for i in range(nn.value):
+        kids[i] = [c for c in (nodes[i].child0, nodes[i].child1) if not (c & LEAF_BIT)]
+    deepest, stack = 0, [(0, 1)]
+    while stack:
+        i, d = stack.pop()
+        deepest = max(deepest, d)
+        stack.extend((c, d + 1) for c in kids[i])
+    assert deepest == depth.value

@@ -16,7 +16,7 @@
 //   K6 k_depth        inner nodes on the longest root path
 //   K7-K11 (default)  the top of the tree by SAH: the radix tree cut into clusters of <= 2048 triangles, an exact sweep-SAH tree over
 //                     the clusters built on the host, the cluster subtrees emitted below it (see "the top of the tree by SAH" below)
-// All HBM-bound streaming or gather work, 5.5 ms of kernels for 10 M triangles (23 ms with the host's SAH over the clusters in between); the rest of the call is moving the
+// All HBM-bound streaming or gather work, 4.1 ms of kernels for 10 M triangles (9 ms with the host's SAH over the clusters in between); the rest of the call is moving the
 // vertices in (360 MB) and the nodes out (< 640 MB) over PCIe.  No MFMA, no LDS tiling: nothing here is a contraction.
 #include <hip/hip_runtime.h>
 
@@ -455,14 +455,24 @@ __global__ __launch_bounds__(256) void k_cluster_depth(const uint32_t* __restric
                                                        const uint32_t* __restrict__ incl, uint32_t n_prims, uint32_t* __restrict__ cdepth)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_prims) return;
-    uint32_t d = 0, node = leaf_parent[p];
-    for (uint32_t guard = 0; guard < 4096u && node != 0xFFFFFFFFu; ++guard) {  // (`keep` is 0 below the leaves' roots and above the cluster's root)
-        if (keep[node]) ++d;
-        else if (d) break;  // past the cluster's root
-        node = parent[node];
+    uint32_t d = 0, c = 0xFFFFFFFFu;
+    if (p < n_prims) {
+        c = incl[p] - 1u;
+        uint32_t node = leaf_parent[p];
+        for (uint32_t guard = 0; guard < 4096u && node != 0xFFFFFFFFu; ++guard) {  // (`keep` is 0 below the leaves' roots and above the cluster's root)
+            if (keep[node]) ++d;
+            else if (d) break;  // past the cluster's root
+            node = parent[node];
+        }
     }
-    if (d && d > cdepth[incl[p] - 1u]) atomicMax(&cdepth[incl[p] - 1u], d);  // (the plain read only saves atomics: thousands of triangles share a cluster's word)
+    // neighbours share clusters: one atomic per run of equal cluster ids in the wave (the lane that starts the run carries the run's maximum)
+    const uint32_t lane = threadIdx.x & 63u;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t od = __shfl_down(d, off), oc = __shfl_down(c, off);
+        if (lane + off < 64u && oc == c) d = od > d ? od : d;
+    }
+    const uint32_t pc = __shfl_up(c, 1);
+    if (p < n_prims && d && (lane == 0u || pc != c)) atomicMax(&cdepth[c], d);
 }
 
 // ---- host: exact sweep SAH over the clusters, cost = half-area x triangles
@@ -471,15 +481,25 @@ struct TopNode {
     float lo[2][3], hi[2][3];
 };
 struct TopBuilder {
+    // The three centre orders are sorted ONCE and kept through the recursion by stable partitions (as host/bvh.cpp does for its exact-SAH
+    // subtrees): a node is evaluated by scanning its range of each order, O(n) per node instead of three to four sorts.
     const std::vector<ClusterRec>& cl;
-    std::vector<uint32_t> idx;
+    std::vector<uint32_t> ord[3], tmp;
+    std::vector<uint8_t> side;
     std::vector<TopNode> nodes;
     std::vector<uint32_t> leaf_order, top_depth;
     std::vector<float> suffix_area;
     std::vector<uint64_t> suffix_count;
-    explicit TopBuilder(const std::vector<ClusterRec>& c) : cl(c), idx(c.size()), top_depth(c.size(), 0), suffix_area(c.size()), suffix_count(c.size())
+    explicit TopBuilder(const std::vector<ClusterRec>& c) : cl(c), tmp(c.size()), side(c.size(), 0), top_depth(c.size(), 0), suffix_area(c.size()), suffix_count(c.size())
     {
-        for (size_t i = 0; i < c.size(); ++i) idx[i] = (uint32_t)i;
+        for (int a = 0; a < 3; ++a) {
+            ord[a].resize(c.size());
+            for (size_t i = 0; i < c.size(); ++i) ord[a][i] = (uint32_t)i;
+            std::sort(ord[a].begin(), ord[a].end(), [&](uint32_t x, uint32_t y) {
+                const float cx = centre(x, a), cy = centre(y, a);
+                return cx < cy || (cx == cy && x < y);
+            });
+        }
     }
     static float halfArea(const float* lo, const float* hi)
     {
@@ -487,18 +507,11 @@ struct TopBuilder {
         return x * y + x * z + y * z;
     }
     float centre(uint32_t c, int a) const { return 0.5f * cl[c].lo[a] + 0.5f * cl[c].hi[a]; }
-    void sortAxis(size_t lo, size_t hi, int a)
-    {
-        std::sort(idx.begin() + (long)lo, idx.begin() + (long)hi, [&](uint32_t x, uint32_t y) {
-            const float cx = centre(x, a), cy = centre(y, a);
-            return cx < cy || (cx == cy && x < y);
-        });
-    }
-    // returns the reference of the subtree over idx[lo, hi) and its bounds; parents before children
+    // returns the reference of the subtree over positions [lo, hi) of the three orders (the same SET in each) and its bounds; parents before children
     int32_t build(size_t lo, size_t hi, uint32_t depth, float* blo, float* bhi)
     {
         if (hi - lo == 1) {
-            const uint32_t c = idx[lo];
+            const uint32_t c = ord[0][lo];
             leaf_order.push_back(c);
             top_depth[c] = depth;
             for (int a = 0; a < 3; ++a) { blo[a] = cl[c].lo[a]; bhi[a] = cl[c].hi[a]; }
@@ -509,11 +522,11 @@ struct TopBuilder {
         int best_axis = -1;
         size_t best_mid = lo + m / 2;
         for (int a = 0; a < 3 && depth < 48; ++a) {  // (a runaway depth: medians from there on, as in host/bvh.cpp)
-            sortAxis(lo, hi, a);
+            const uint32_t* o = ord[a].data() + lo;
             float l3[3] = {3.0e38f, 3.0e38f, 3.0e38f}, h3[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
             uint64_t cnt = 0;
             for (size_t i = m; i-- > 1;) {
-                const ClusterRec& r = cl[idx[lo + i]];
+                const ClusterRec& r = cl[o[i]];
                 for (int k = 0; k < 3; ++k) { l3[k] = std::fmin(l3[k], r.lo[k]); h3[k] = std::fmax(h3[k], r.hi[k]); }
                 cnt += r.count;
                 suffix_area[i] = halfArea(l3, h3);
@@ -522,7 +535,7 @@ struct TopBuilder {
             for (int k = 0; k < 3; ++k) { l3[k] = 3.0e38f; h3[k] = -3.0e38f; }
             cnt = 0;
             for (size_t i = 1; i < m; ++i) {
-                const ClusterRec& r = cl[idx[lo + i - 1]];
+                const ClusterRec& r = cl[o[i - 1]];
                 for (int k = 0; k < 3; ++k) { l3[k] = std::fmin(l3[k], r.lo[k]); h3[k] = std::fmax(h3[k], r.hi[k]); }
                 cnt += r.count;
                 const float cost = halfArea(l3, h3) * (float)cnt + suffix_area[i] * (float)suffix_count[i];
@@ -530,7 +543,16 @@ struct TopBuilder {
             }
         }
         if (best_axis < 0) { best_axis = 0; best_mid = lo + m / 2; }
-        if (best_axis != 2) sortAxis(lo, hi, best_axis);
+        for (size_t i = lo; i < hi; ++i) side[ord[best_axis][i]] = i < best_mid ? 0 : 1;
+        for (int a = 0; a < 3; ++a) {
+            if (a == best_axis) continue;
+            size_t l = lo, r = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                const uint32_t c = ord[a][i];
+                if (side[c]) tmp[r++] = c; else ord[a][l++] = c;  // (l <= i: nothing unread is overwritten)
+            }
+            for (size_t k = 0; k < r; ++k) ord[a][l + k] = tmp[k];
+        }
         const int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
         float l0[3], h0[3], l1[3], h1[3];
