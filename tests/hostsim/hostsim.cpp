@@ -298,6 +298,73 @@ extern "C" int hostsim_trace_counts(const trt_scene* s, int nk, uint64_t n, cons
     return 0;
 }
 
+// The sequence of steps the wave driver takes for one ray on the oct nodes (tools/pool_sim.py: what would grouping rays by phase across the waves
+// of a block buy?): per ray up to `cap` bytes, 0 = a node step, k = 1..2 = a leaf step that tests k triangles (the driver tests up to two of
+// the lane's group per leaf step).  The loop is traceOctPass's (trt_oct.h) with a tape; `t_init` / `redo` / `light` as for a parity-mode shadow ray
+// (light < 0: a closest-hit ray).
+extern "C" int hostsim_oct_step_tape(const trt_scene* s, uint64_t n, const float* org, const float* dir, const float* t_init, int light, uint32_t cap, uint8_t* tape, uint32_t* len)
+{
+    const int old = g_node_kind;
+    g_node_kind = 1;
+    HostScene hs(s);
+    g_node_kind = old;
+    if (!hs.nk) return 1;
+    const LightBox* lbox = light >= 0 && (uint32_t)light < hs.light_boxes.size() ? &hs.light_boxes[(size_t)light] : nullptr;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long long i = 0; i < (long long)n; ++i) {
+        OctArrayStack stk;
+        const f3 o = ld3(org + i * 3), d = ld3(dir + i * 3);
+        uint8_t* out = tape + (size_t)i * cap;
+        uint32_t m = 0;
+        auto put = [&](uint8_t v) { if (m < cap) out[m] = v; ++m; };
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const OctRay R = makeOctRay(o, d, inv);
+        float best_t = t_init ? t_init[i] : TRT_INF, stop_t = -TRT_INF;
+        int32_t best_tri = -1;
+        uint32_t best_flags = 0u;
+        bool skip = false;
+        if (lbox) {
+            float e;
+            if (!boxTest(lbox->lo[0], lbox->lo[1], lbox->lo[2], lbox->hi[0], lbox->hi[1], lbox->hi[2], o, inv, e)) skip = true;
+            stop_t = trt_leaf_floor(e, hs.sc.leaf_alpha);
+        }
+        for (int pass = 0; pass < 2 && !skip; ++pass) {
+            int sp = 0;
+            OctGroup ng, tg;
+            ng.x = 0u; ng.y = 0x80000000u;
+            tg.x = 0u; tg.y = 0u;
+            bool stop = false;
+            for (;;) {
+                if (ng.y & 0xFF000000u) {
+                    const uint32_t ni = octNextChild(ng, R);
+                    if (ng.y & 0xFF000000u) stk.push(sp++, ng);
+                    put(0);
+                    octVisit(hs.sc.onodes, ni, R, trt_cull_bound(best_t, hs.sc.leaf_alpha), ng, tg);
+                }
+                uint32_t in_step = 0;
+                while (tg.y) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(tg.y);
+                    tg.y &= tg.y - 1u;
+                    const TriIsect T = hs.sc.tri_trav[tg.x + b];
+                    float t, un, vn, det;
+                    if (triTest(T, o, d, t, un, vn, det)) octFold(t, f2u(T.c.w), f2u(T.c.z), best_t, best_tri, best_flags);
+                    if (++in_step == 2u || !tg.y) { put((uint8_t)in_step); in_step = 0; }
+                    if (lbox && best_tri >= 0 && best_t < stop_t && in_step == 0u) { tg.y = 0u; stop = true; }
+                }
+                if (stop) break;
+                if (!(ng.y & 0xFF000000u)) {
+                    if (sp == 0) break;
+                    ng = stk.pop(--sp);
+                }
+            }
+            if (stop || !t_init || best_tri >= 0 || !(best_t < TRT_INF)) break;
+            best_t = TRT_INF;  // nothing in front of the hint: search again without it
+        }
+        len[i] = m;
+    }
+    return 0;
+}
+
 // divMagic(n, d, magicOf(d)) against n / d for a list of numerators: returns the number of mismatches (tests/test_hostsim_parity.py)
 extern "C" uint64_t hostsim_div_magic_mismatches(uint32_t d, const uint32_t* n, uint64_t count)
 {
