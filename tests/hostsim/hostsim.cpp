@@ -302,7 +302,7 @@ extern "C" int hostsim_trace_counts(const trt_scene* s, int nk, uint64_t n, cons
 // of a block buy?): per ray up to `cap` bytes, 0 = a node step, k = 1..2 = a leaf step that tests k triangles (the driver tests up to two of
 // the lane's group per leaf step).  The loop is traceOctPass's (trt_oct.h) with a tape; `t_init` / `redo` / `light` as for a parity-mode shadow ray
 // (light < 0: a closest-hit ray).
-extern "C" int hostsim_oct_step_tape(const trt_scene* s, uint64_t n, const float* org, const float* dir, const float* t_init, int light, uint32_t cap, uint8_t* tape, uint32_t* len)
+extern "C" int hostsim_oct_step_tape_chunk(const trt_scene* s, uint64_t n, const float* org, const float* dir, const float* t_init, int light, uint32_t cap, uint8_t* tape, uint32_t* len, uint32_t per_leaf_step)
 {
     const int old = g_node_kind;
     g_node_kind = 1;
@@ -348,7 +348,7 @@ extern "C" int hostsim_oct_step_tape(const trt_scene* s, uint64_t n, const float
                     const TriIsect T = hs.sc.tri_trav[tg.x + b];
                     float t, un, vn, det;
                     if (triTest(T, o, d, t, un, vn, det)) octFold(t, f2u(T.c.w), f2u(T.c.z), best_t, best_tri, best_flags);
-                    if (++in_step == 2u || !tg.y) { put((uint8_t)in_step); in_step = 0; }
+                    if (++in_step == per_leaf_step || !tg.y) { put((uint8_t)in_step); in_step = 0; }
                     if (lbox && best_tri >= 0 && best_t < stop_t && in_step == 0u) { tg.y = 0u; stop = true; }
                 }
                 if (stop) break;
@@ -363,6 +363,11 @@ extern "C" int hostsim_oct_step_tape(const trt_scene* s, uint64_t n, const float
         len[i] = m;
     }
     return 0;
+}
+
+extern "C" int hostsim_oct_step_tape(const trt_scene* s, uint64_t n, const float* org, const float* dir, const float* t_init, int light, uint32_t cap, uint8_t* tape, uint32_t* len)
+{
+    return hostsim_oct_step_tape_chunk(s, n, org, dir, t_init, light, cap, tape, len, 2u);  // TRT_OCT_LEAF_LOOP
 }
 
 // divMagic(n, d, magicOf(d)) against n / d for a list of numerators: returns the number of mismatches (tests/test_hostsim_parity.py)
