@@ -48,8 +48,9 @@ int trth_scene_build(trth_scene* s, int leaf_num, int builder);
 
 /* The other way to a built scene: a tree from another builder (the GPU builder of trt_build.h).  trth_scene_vertices copies the
  * vertices of the triangles in their current order (n_triangles * 9 floats: what that builder takes); trth_scene_adopt_bvh
- * reorders the triangles — position i gets the triangle that stood at order[i], the in-place sort of buildBVH (bvh.cpp:16-144) as
- * one permutation — installs the nodes and flattens.  The tree is not checked here: trt_create validates every tree it is given. */
+ * installs the nodes and flattens with the triangles in the builder's order — position i of the flat arrays gets the triangle
+ * that stands at order[i], the in-place sort of buildBVH (bvh.cpp:16-144) as one permutation (the scene's own triangle list
+ * keeps its order: only the flat scene is what trt_create sees).  The tree is not checked here: trt_create validates every tree it is given. */
 int trth_scene_vertices(const trth_scene* s, float* out, uint64_t capacity_floats);
 int trth_scene_adopt_bvh(trth_scene* s, const trt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* order, uint32_t depth);
 

@@ -456,7 +456,7 @@ FlatBVH buildBVH(std::vector<Triangle>& triangles, int leaf_num, BvhBuilder buil
     return out;
 }
 
-void FlatScene::build(const Scene& scene, const FlatBVH& bvh)
+void FlatScene::build(const Scene& scene, const FlatBVH& bvh, const uint32_t* order)
 {
     const size_t n = scene.triangles.size();
     tri_v.resize(n * 9);
@@ -467,7 +467,7 @@ void FlatScene::build(const Scene& scene, const FlatBVH& bvh)
     const int threads = builderThreads();
 #pragma omp parallel for schedule(static) num_threads(threads) if (n >= 100000)
     for (size_t i = 0; i < n; ++i) {
-        const Triangle& t = scene.triangles[i];
+        const Triangle& t = scene.triangles[order ? order[i] : i];
         for (int k = 0; k < 3; ++k) {
             tri_v[i * 9 + k * 3 + 0] = t.v[k].x; tri_v[i * 9 + k * 3 + 1] = t.v[k].y; tri_v[i * 9 + k * 3 + 2] = t.v[k].z;
             tri_vn[i * 9 + k * 3 + 0] = t.vn[k].x; tri_vn[i * 9 + k * 3 + 1] = t.vn[k].y; tri_vn[i * 9 + k * 3 + 2] = t.vn[k].z;

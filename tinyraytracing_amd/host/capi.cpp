@@ -110,8 +110,7 @@ int trth_scene_vertices(const trth_scene* s, float* out, uint64_t capacity_float
 int trth_scene_adopt_bvh(trth_scene* s, const trt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* order, uint32_t depth)
 {
     if (!s || !nodes || !order || n_nodes < 1) return fail("trth_scene_adopt_bvh: null argument");
-    auto& t = s->scene.triangles;
-    const size_t n = t.size();
+    const size_t n = s->scene.triangles.size();
     {   // `order` must be a permutation of the triangles
         std::vector<uint8_t> used(n, 0);
         for (size_t i = 0; i < n; ++i) {
@@ -120,14 +119,12 @@ int trth_scene_adopt_bvh(trth_scene* s, const trt_bvh_node* nodes, uint32_t n_no
         }
     }
     try {
-        std::vector<trt::Triangle> sorted(n);
-#pragma omp parallel for schedule(static) num_threads(trt::hostThreads()) if (n >= 100000)
-        for (size_t i = 0; i < n; ++i) sorted[i] = std::move(t[order[i]]);  // a permutation: every source moved once
-        t.swap(sorted);
+        // The flat arrays are gathered through `order`; the scene's Triangle objects stay where they are (moving 10 M of them costs more
+        // than the GPU build saved, and nothing reads their order once the scene is flat).
         s->bvh.nodes.assign(nodes, nodes + n_nodes);
         s->bvh.depth = depth;
         s->flat.reset(new trt::FlatScene);
-        s->flat->build(s->scene, s->bvh);
+        s->flat->build(s->scene, s->bvh, order);
     } catch (const std::exception& e) {
         s->flat.reset();
         return fail(e);

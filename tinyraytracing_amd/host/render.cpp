@@ -77,6 +77,7 @@ void writeCheckpoint(const std::string& path, const Checkpoint& head, const std:
 void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stats)
 {
     FlatBVH bvh;
+    std::vector<uint32_t> gpu_order;
     if (opts.gpu_builder) {
         // buildBVH on the device (main.cpp:76): the nodes, and the permutation that is the reference's in-place sort of scene.triangles
         const size_t n = scene.triangles.size();
@@ -94,14 +95,12 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
         if (trt_build_lbvh(v.data(), (uint32_t)n, opts.leaf_num, dev, bvh.nodes.data(), (uint32_t)bvh.nodes.size(), &n_nodes, order.data(), &bvh.depth, nullptr) != TRT_OK)
             throw std::runtime_error(std::string("trt_build_lbvh: ") + trt_build_last_error());
         bvh.nodes.resize(n_nodes);
-        std::vector<Triangle> sorted(n);
-        for (size_t i = 0; i < n; ++i) sorted[i] = std::move(scene.triangles[order[i]]);
-        scene.triangles.swap(sorted);
+        gpu_order.swap(order);  // the flat arrays are gathered through it below: position i = scene.triangles[order[i]]
     } else {
         bvh = buildBVH(scene.triangles, opts.leaf_num, opts.builder);
     }
     FlatScene flat;
-    flat.build(scene, bvh);
+    flat.build(scene, bvh, gpu_order.empty() ? nullptr : gpu_order.data());
 
     trt_params p{};
     p.width = scene.img_width;

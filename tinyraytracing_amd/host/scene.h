@@ -72,8 +72,10 @@ public:
     FlatScene(const FlatScene&) = delete;
     FlatScene& operator=(const FlatScene&) = delete;
 
-    // scene.triangles must already be in BVH order (buildBVH ran).
-    void build(const Scene& scene, const FlatBVH& bvh);
+    // scene.triangles must already be in BVH order (buildBVH ran) — or `order` says where position i's triangle stands in
+    // scene.triangles (a tree from another builder, trt_build.h: the flat arrays are gathered through it and the 10 M Triangle
+    // objects of a big scene stay where they are).
+    void build(const Scene& scene, const FlatBVH& bvh, const uint32_t* order = nullptr);
     const trt_scene* c_scene() const { return &flat; }
 
     std::vector<float> tri_v, tri_vn, tri_vt;

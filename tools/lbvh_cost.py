@@ -41,7 +41,7 @@ def main():
             t = time.time()
             r.render(T.make_params(w, h, spp, 11))
             ms = (time.time() - t) * 1e3
-            extra = f" (device {s.build_ms[0]:.1f} ms, call {s.build_ms[1]:.0f} ms, rest = vertices out of / triangles reordered in the host scene)" if builder != "auto" else ""
+            extra = f" (device {s.build_ms[0]:.1f} ms, call {s.build_ms[1]:.0f} ms, rest = vertices out of the host scene, its flattening through the returned order)" if builder != "auto" else ""
             print(f"{name} {f.n_tris} triangles, {builder:5s}: build {t_build:.2f} s{extra}, {f.n_nodes} nodes depth {f.bvh_depth}, trt_create {t_create:.2f} s, "
                   f"visits/ray {(st.inner_visits[0] + st.inner_visits[1]) / rays:.2f} tests/ray {(st.tri_tests[0] + st.tri_tests[1]) / rays:.2f}, "
                   f"{w}x{h} {spp} spp: {ms:.1f} ms = {rays / ms / 1e3:.0f} Mrays/s", flush=True)
