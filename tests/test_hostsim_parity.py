@@ -295,3 +295,27 @@ def test_the_collapses_do_not_depend_on_the_number_of_host_threads(name, kw):
     for threads in (2, 3, 7):
         assert H.tree_hashes(s.flat, threads) == ref, threads
     s.close()
+
+
+def test_step_tape_agrees_with_the_visit_counters():
+    """tools/pool_sim.py feeds on the per-ray tape of steps of the oct traversal (hostsim_oct_step_tape): its node steps are the traversal's node
+    visits, its leaf steps add up to the traversal's triangle tests, two at most per step (the wave driver's leaf loop)."""
+    import ctypes as C
+    s = T.Scene.named("staircase", 64, 36)
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(20000, lo, hi, seed=8)
+    v, t = H.trace_counts(s.flat, 1, org, dirs)
+    lib = H.lib()
+    lib.hostsim_oct_step_tape.argtypes = [C.c_void_p, C.c_uint64, H.fp, H.fp, H.fp, C.c_int, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]
+    cap = 255
+    tape = np.zeros((len(org), cap), np.uint8)
+    ln = np.zeros(len(org), np.uint32)
+    o = np.ascontiguousarray(org, np.float32)
+    d = np.ascontiguousarray(dirs, np.float32)
+    assert lib.hostsim_oct_step_tape(C.cast(s.flat, C.c_void_p), len(o), o.ctypes.data_as(H.fp), d.ctypes.data_as(H.fp), None, -1, cap, tape.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                     ln.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+    assert ln.max() <= cap
+    valid = np.arange(cap)[None, :] < ln[:, None]
+    assert np.array_equal(((tape == 0) & valid).sum(1), v)
+    assert np.array_equal((tape * valid).sum(1), t) and tape.max() <= 2
+    s.close()
