@@ -51,12 +51,15 @@ $(OUT)/libtrt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
+# -ffp-contract=off like every other library here: contraction would only move Morton codes and SAH costs, i.e. topology, but the tree is part of
+# the checkpoint's scene hash and should not depend on the compiler's choice of fused operations.
 $(OUT)/libtrt_lbvh.so: $(PKG)/csrc/trt_lbvh.hip include/trt.h include/trt_build.h
 	@mkdir -p $(OUT)
-	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wextra -Wno-unused-parameter -Iinclude -shared -o $@ $(PKG)/csrc/trt_lbvh.hip
+	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wextra -Wno-unused-parameter -Iinclude -shared -o $@ $(PKG)/csrc/trt_lbvh.hip
 
-$(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) include/trt_build.h $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so $(OUT)/libtrt_lbvh.so
-	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -ltrt_lbvh -fopenmp -Wl,-rpath,'$$ORIGIN'
+# tinyrt does not link libtrt_lbvh.so: render() dlopens it when --gpu-bvh asks for the device builder (include/trt_build.h)
+$(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) include/trt_build.h $(OUT)/libtrt_host.so $(OUT)/libtrt_hip.so
+	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/main.cpp $(PKG)/host/render.cpp -L$(OUT) -ltrt_host -ltrt_hip -fopenmp -ldl -Wl,-rpath,'$$ORIGIN'
 
 # A/B builds of the HIP library for tuning on the GPU box: TRT_HIP_LIB=<path> selects one at run time.
 # name=defines, "+" separating the -D options

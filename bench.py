@@ -111,7 +111,7 @@ class Bench:
         T, D, torch, a = self.T, self.D, self.torch, self.a
         world, rank, local_rank, dist = self.world, self.rank, self.local_rank, self.dist
         t0 = time.time()
-        scene = T.Scene.named(scene_name, width, height, leaf_num=leaf, n=tris, builder=builder or a.builder)
+        scene = T.Scene.named(scene_name, width, height, leaf_num=leaf, n=tris, builder=builder or a.builder, device=local_rank)
         t_load = time.time() - t0
         renderer = T.Renderer(scene, local_rank)
         budget = int(a.mem_gb * (1 << 30))
@@ -134,7 +134,9 @@ class Bench:
         out = torch.empty((nrows, width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
         stream = torch.cuda.current_stream().cuda_stream
 
-        def step(flags):
+        step_times = D.StepTimes()  # this rank's marks of the TIMED steps only (render | gather + un-interleave)
+
+        def step(flags, times=None):
             if group is not None:
                 pg = T.make_params(width, height, spp, seed, flags=flags, mem_budget=budget)
                 st_g, _ = group.render_into(pg, out)
@@ -143,7 +145,7 @@ class Bench:
             def fn(pp):
                 return out, renderer.render_into(pp, out, stream)
             # every rank renders its stripes, then ONE gather of the packed stripes to rank 0
-            return D.render_distributed(fn, width, height, spp, seed, dist=dist, device=f"cuda:{local_rank}", flags=flags, mem_budget=budget)
+            return D.render_distributed(fn, width, height, spp, seed, dist=dist, device=f"cuda:{local_rank}", flags=flags, mem_budget=budget, times=times)
 
         img, st_count = step(flags_count)  # inner-node visits / triangle tests for the algorithmic bytes
         for _ in range(max(warmup - 1, 0)):
@@ -154,20 +156,21 @@ class Bench:
         render_ms = 0.0
         st = st_count
         for _ in range(steps):
-            img, st = step(flags_time)
+            img, st = step(flags_time, step_times)
             rays_rank += st.rays
             render_ms += st.render_ms
         self.sync()
         elapsed = time.perf_counter() - t_begin
+        rank_render_ms, rank_gather_ms = step_times.totals_ms() if group is None else (0.0, 0.0)
         # the profiling step: the same render once more with hipEvents around every launch (on the launch stream, inside the
         # library); its per-kernel sums are scaled to `steps` so that every per-step figure below keeps its meaning
         img, st_prof = step(flags_prof)
         self.sync()
         kernel_ms = [st_prof.kernel_ms[k] * steps for k in range(8)]
         launches = [st_prof.launches[k] * steps for k in range(8)]
-        # --also-overlap: beside the contract's number, the same steps with two sample passes in flight
-        # (TRT_FLAG_OVERLAP, what render()/tinyrt use).  Not `value`: per-kernel hipEvent times of overlapping passes
-        # contain each other.  Off by default so that a rocprofv3 run of the default command sees the timed launches only.
+        # beside the contract's number, the same steps with two sample passes in flight (TRT_FLAG_OVERLAP, what render()/tinyrt
+        # use).  Not `value`: per-kernel hipEvent times of overlapping passes contain each other.  On by default at N = 1
+        # (--no-overlap-extra skips it, e.g. so that a rocprofv3 run of the command sees the timed launches and the profiling step only).
         overlap_extra = None
         if world == 1 and also_overlap and not (base_flags & T.TRT_FLAG_OVERLAP) and spp >= 2:
             step(T.TRT_FLAG_OVERLAP | fx)
@@ -187,8 +190,17 @@ class Bench:
             rr = torch.tensor([rays_rank], dtype=torch.int64, device=red_dev)
             dist.all_reduce(rr)
             rays_total = int(rr.item())
+            # every rank's own step, for the first run on a real node: [device render ms (trt_stats), render ms and gather ms between this
+            # rank's marks (a rank that finishes early waits in the gather), k_tail ms, rays] per step
+            mine = torch.tensor([render_ms / steps, rank_render_ms / steps, rank_gather_ms / steps, st_prof.kernel_ms[T.KERNEL_NAMES.index("tail")] if "tail" in T.KERNEL_NAMES else 0.0,
+                                 rays_rank / steps], dtype=torch.float64, device=red_dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank = [{"rank": r, "device_render_ms": round(float(v[0]), 3), "render_ms": round(float(v[1]), 3), "gather_wait_ms": round(float(v[2]), 3),
+                         "tail_ms": round(float(v[3]), 3), "rays_per_step": int(v[4])} for r, v in enumerate(every)]
         else:
             rays_total = rays_rank
+            per_rank = None
         res = None
         if rank == 0:
             mrays = rays_total / elapsed / 1e6
@@ -243,6 +255,10 @@ class Bench:
                     "tri_tests_per_ray": round((st_count.tri_tests[0] + st_count.tri_tests[1]) / max(st_count.rays, 1), 2)},
                 "roofline": roofline, "kernels_rank0": kernels, "passes": st.passes, "max_path_vertices": st.max_bounces + 1,
                 "scene_load_build_s": round(t_load, 2), "with_pass_overlap": overlap_extra,
+                # how the numbers above were taken (rounds 1-2 had hipEvents around every launch of the timed steps; since round 3 they have none)
+                "timing": {"events_in_timed_steps": False, "kernel_ms_from": f"1 profiling step (TRT_FLAG_TIMING) after the timed region x {steps}",
+                           "value_from": "wall clock of the timed steps between barriers, max over ranks"},
+                "per_rank": per_rank,
             }
             if save_png and img is not None:
                 T.imshow(img.cpu().numpy(), save_png)

@@ -29,6 +29,9 @@ typedef struct oracle_stats {
 #define ORACLE_MODE_EXPERIMENT_NO_RR_DIV 0x100 /* or-ed into `mode` (iterative form): the estimator WITHOUT the 1 / P_RR of pathTracing.cpp:84 — an
                                                 * experiment of tests/test_ref_png.py against the reference's older `back` snapshots, never the parity path.
                                                 * An explicit argument: no environment variable can change what this library computes. */
+#define ORACLE_MODE_EXPERIMENT_SPECULAR_KS 0x200 /* or-ed into `mode` (iterative form): a SPECULAR bounce weighted by the material's Ks instead of the texel Kd that
+                                                  * pathTracing.cpp:91-93 multiplies by (Q8) — an experiment against the reference's staircase snapshots, whose teal
+                                                  * Metal strip (Kd 0.2, Ks 0 0.8 0.8) the committed weighting cannot produce; never the parity path. */
 
 /* main.cpp:80-113 restated.  Same trt_params semantics as trt_render (tile,
  * row interleave, packed float output).  threads <= 0 -> all cores. */

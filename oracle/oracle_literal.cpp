@@ -497,6 +497,11 @@ int oracle_render_literal(const trt_scene* scene, const trt_params* p, float* ou
  *   ORACLE_EXP_SHARED_ENGINES: one thread; the draws come from the reference's five engines (struct Engines): main's seeded p->seed,
  *     shade's, Sample's and nextRay's ALL seeded p->seed + 1 (identical streams, as time(NULL) leaves them), RR's default-seeded.
  *   ORACLE_EXP_INDEPENDENT_ENGINES: the same with three different seeds (the control: what changing the generator alone does). */
+#ifndef ORACLE_EXPERIMENTS
+/* liboracle.so — the library every parity test loads — does not contain the experiments (one of them is a deliberate data race);
+ * oracle/Makefile builds them into liboracle_exp.so (-DORACLE_EXPERIMENTS), which only tests/test_ref_png.py's experiment tests load. */
+int oracle_render_literal_experiment(const trt_scene*, const trt_params*, float*, int, int) { return TRT_EINVAL; }
+#else
 int oracle_render_literal_experiment(const trt_scene* scene, const trt_params* p, float* out_rgb, int threads, int experiment)
 {
     if (!scene || !p || !out_rgb) return TRT_EINVAL;
@@ -543,6 +548,7 @@ int oracle_render_literal_experiment(const trt_scene* scene, const trt_params* p
     for (size_t i = 0; i < image.size(); ++i) out_rgb[i] = (float)image[i];
     return TRT_OK;
 }
+#endif  /* ORACLE_EXPERIMENTS */
 
 /* interactTriangle + findBaryCor of the reference on one triangle: returns 1 on hit, out = {t, b0, b1, b2}. */
 int oracle_tri_test_literal(const float v[9], const float o[3], const float d[3], float out[4])

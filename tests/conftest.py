@@ -17,6 +17,7 @@ def _ensure_built():
     need = [os.path.join(ROOT, "tinyraytracing_amd", "lib", "libtrt_host.so"),
             os.path.join(ROOT, "tinyraytracing_amd", "lib", "libtrt_hip.so"),
             os.path.join(ROOT, "oracle", "liboracle.so"),
+            os.path.join(ROOT, "oracle", "liboracle_exp.so"),
             os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")]
     if all(os.path.exists(p) for p in need):
         return

@@ -13,6 +13,7 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 
 MODE_ITERATIVE, MODE_RECURSIVE = 0, 1
 MODE_EXPERIMENT_NO_RR_DIV = 0x100  # or-ed into `mode`: oracle.h
+MODE_EXPERIMENT_SPECULAR_KS = 0x200
 TRACE_REFERENCE, TRACE_BRUTE = 0, 1
 
 
@@ -91,12 +92,24 @@ def render_literal(flat, params, threads=0):
 
 
 EXP_RACY_ACCUM, EXP_SHARED_ENGINES, EXP_INDEPENDENT_ENGINES = 1, 2, 3
+ORACLE_EXP_SO = os.path.join(ROOT, "oracle", "liboracle_exp.so")
+_exp_lib = None
+
+
+def exp_lib():
+    """oracle/liboracle_exp.so: the oracle's sources built with -DORACLE_EXPERIMENTS.  Only the experiment tests load it; the
+    library behind every parity test (liboracle.so) contains no data race."""
+    global _exp_lib
+    if _exp_lib is None:
+        _exp_lib = C.CDLL(ORACLE_EXP_SO)
+    return _exp_lib
+
 
 
 def render_literal_experiment(flat, params, experiment, threads=0):
     """oracle_render_literal_experiment (oracle.h): the reference's racy accumulation / its shared random engines.  Whole image."""
     out = np.empty((params.height, params.width, 3), np.float32)
-    L = lib()
+    L = exp_lib()
     L.oracle_render_literal_experiment.argtypes = [C.POINTER(SceneFlat), C.POINTER(Params), fp, C.c_int, C.c_int]
     rc = L.oracle_render_literal_experiment(flat, C.byref(params), out.ctypes.data_as(fp), int(threads), int(experiment))
     if rc != 0:

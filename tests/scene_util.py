@@ -119,3 +119,20 @@ def renumber_nodes_reversed(scene):
                     backwards += 1
         C.memmove(C.byref(f.nodes[new_index[old]]), C.byref(node), C.sizeof(BvhNode))
     return backwards
+
+
+def load_with_reference_tree(name, width=0, height=0, leaf_num=8):
+    """A shipped scene with the tree the REFERENCE's builder gives it: oracle_build_bvh restates buildBVH (bvh.cpp:16-144, called
+    with leaf 8 at main.cpp:76); the scene adopts its nodes and triangle order the way a caller's own tree arrives at trt_create."""
+    import ctypes as C
+    import numpy as np
+    import oracle_lib as O
+    d = os.path.join(T.SCENES_DIR, name)
+    s = T.Scene.load(os.path.join(d, name + ".xml"), os.path.join(d, name + ".obj"), os.path.join(d, name + ".mtl"), d, width, height)
+    n = s.info["n_triangles"]
+    v = np.empty(n * 9, np.float32)
+    s._check(s._lib.trth_scene_vertices(s._h, v.ctypes.data_as(C.POINTER(C.c_float)), v.size))
+    perm, nodes, n_nodes, depth = O.build_bvh(v.reshape(n, 9), leaf_num)
+    s._check(s._lib.trth_scene_adopt_bvh(s._h, nodes, n_nodes, perm.ctypes.data_as(C.POINTER(C.c_uint32)), depth))
+    s._built = True
+    return s

@@ -121,7 +121,7 @@ def test_tiny_scene_uniform_walk_and_forced_per_ray_traversal(monkeypatch):
     s = get_scene("back", 64, 64)
     p = T.make_params(64, 64, 8, 5)
     ref, _ = O.render(s.flat, p)
-    for impl, nk, nbytes in (("0", "0", 64), ("3", "0", 128), ("3", "1", 128)):  # leaves of 8 triangles: no oct tree, the exact nodes serve
+    for impl, nk, nbytes in (("0", "0", 64), ("3", "0", 128), ("3", "1", 80)):  # leaves of 8 triangles: several slots of the oct nodes each (round 4)
         monkeypatch.setenv("TRT_TRACE_IMPL", impl)
         monkeypatch.setenv("TRT_NODE_KIND", nk)
         r = T.Renderer(s, 0)
@@ -725,6 +725,38 @@ def test_compressed_nodes_on_the_gpu(name, monkeypatch):
         finally:
             r.close()
     assert visits["1"] <= visits["0"]  # eight children per visit
+
+
+@pytest.mark.parametrize("name,tree", [("veach-mis", "reference-8"), ("staircase", "reference-8"), ("staircase", "sah-8"), ("veach-mis", "sah-15"), ("back", "sah-8")])
+def test_the_references_own_leaf_size_takes_the_oct_nodes(name, tree, monkeypatch):
+    """main.cpp:76 builds with up to 8 triangles per leaf.  That tree — from the reference's builder as the oracle restates it
+    (bvh.cpp:16-144), or from this repository's with leaf_num 8 / 15 — is walked on the 80-B 8-wide nodes like any other (a leaf of more
+    than 3 triangles = several slots with the leaf's own box, trt_oct_build.h): random, degenerate and grazing rays, then an image and its
+    ray counts, against the oracle on the caller's tree, bit for bit."""
+    if name == "back":
+        monkeypatch.setenv("TRT_TRACE_IMPL", "3")  # the per-lane driver on the tiny tree (it walks the wave-uniform form otherwise)
+    s = SU.load_with_reference_tree(name, 96, 54, 8) if tree == "reference-8" else T.Scene.named(name, 96, 54, leaf_num=int(tree.split("-")[1]))
+    lo, hi = raygen.scene_bounds(s)
+    org, dirs = raygen.random_rays(100000, lo - 5, hi + 5, seed=18)
+    o2, d2 = raygen.adversarial_rays(s, 20000)
+    o3, d3 = raygen.grazing_rays(s.flat, 50000, seed=13)
+    allo, alld = np.vstack([org, o2, o3]), np.vstack([dirs, d2, d3])
+    t0, tri0, uv0 = O.trace(s.flat, allo, alld)
+    p = T.make_params(96, 54, 8, T.SEED_STAIRCASE)
+    ref, ost = O.render(s.flat, p)
+    r = T.Renderer(s, 0)
+    try:
+        t1, tri1, uv1, st = r.trace_closest(allo, alld, want_stats=True)
+        assert st.inner_node_bytes == 80
+        assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+        img, rst = r.render(p)
+        assert_same_image(img, ref, f"{name} {tree}")
+        assert (rst.rays_camera, rst.rays_shadow, rst.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
+        pf = T.make_params(96, 54, 4, 12, flags=T.TRT_FLAG_FIXED_NEE | T.TRT_FLAG_RAY_OFFSET)
+        assert_same_image(r.render(pf)[0], O.render(s.flat, pf)[0], f"{name} {tree} fixed NEE")
+    finally:
+        r.close()
+        s.close()
 
 
 def test_redo_path_is_counted_and_rare():

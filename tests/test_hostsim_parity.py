@@ -319,3 +319,79 @@ def test_step_tape_agrees_with_the_visit_counters():
     assert np.array_equal(((tape == 0) & valid).sum(1), v)
     assert np.array_equal((tape * valid).sum(1), t) and tape.max() <= 2
     s.close()
+
+
+def _large_leaf_scene(name, tree, w, h):
+    import scene_util as SU
+    if tree == "reference-8":
+        return SU.load_with_reference_tree(name, w, h, 8)
+    return T.Scene.named(name, w, h, leaf_num=int(tree.split("-")[1]))
+
+
+@pytest.mark.parametrize("name,tree", [("veach-mis", "reference-8"), ("staircase", "reference-8"), ("staircase", "sah-8"), ("veach-mis", "sah-15"), ("staircase", "sah-5")])
+def test_trees_with_large_leaves_walk_the_oct_nodes(name, tree):
+    """The reference builds its tree with up to 8 triangles per leaf (main.cpp:76).  Such a tree — the reference builder's own, restated
+    in the oracle, or this repository's with leaf_num 5 / 8 / 15 — gets the 8-wide nodes too: a leaf of more than 3 triangles is laid out
+    as several slots that all carry the leaf's own box (trt_oct_build.h), the tie rule and the check of the result keep speaking of the
+    caller's leaf.  Hits, barycentrics, image and ray counts equal the oracle's on the caller's tree, grazing and degenerate rays included."""
+    s = _large_leaf_scene(name, tree, 64, 36)
+    old = H.set_node_kind(1)
+    try:
+        assert H.compressible(s.flat)
+        info = H.oct_info(s.flat)
+        assert info is not None and info[2] == s.info["n_triangles"]
+        org, dirs = raygen.adversarial_rays(s, 15000)
+        lo, hi = raygen.scene_bounds(s)
+        o2, d2 = raygen.random_rays(15000, lo - 5, hi + 5, seed=4)
+        o3, d3 = raygen.grazing_rays(s.flat, 15000, seed=9)
+        org, dirs = np.vstack([org, o2, o3]), np.vstack([dirs, d2, d3])
+        t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+        t1, tri1, uv1, _ = H.trace(s.flat, org, dirs)
+        assert np.array_equal(t0, t1) and np.array_equal(tri0, tri1) and np.array_equal(uv0, uv1)
+        p = T.make_params(64, 36, 3, 11)
+        img, rays = H.render(s.flat, p)
+        ref, st = O.render(s.flat, p)
+        assert np.array_equal(img, ref) and rays == [st.rays_camera, st.rays_shadow, st.rays_indirect]
+        # the same triangles are tested as on the exact 4-wide nodes of the same tree, give or take the culling order
+        v1, n1 = H.trace_counts(s.flat, 1, o2, d2)
+        v0, n0 = H.trace_counts(s.flat, 0, o2, d2)
+        assert v1.sum() < v0.sum() and n1.sum() <= 1.3 * n0.sum()
+    finally:
+        H.set_node_kind(old)
+        s.close()
+
+
+def test_equal_distance_hits_inside_one_large_leaf(tmp_path):
+    """bvh.cpp:219 inside a leaf (the first of several equally distant triangles, unless a later one is emissive: then the last
+    emissive one) and bvh.cpp:168-172 between leaves, on a leaf of 8 coincident triangles that the oct nodes hold as three slots
+    entered in octant order: every stacking order of lamp and white quads gives the oracle's triangle, from both sides."""
+    import scene_util as SU
+    for k, mats in enumerate([("white", "lamp", "white", "lamp"), ("lamp", "white", "white", "white"), ("white", "white", "white", "white"),
+                              ("lamp", "lamp", "white", "lamp"), ("white", "white", "lamp", "white")]):
+        lines, body, vb = ["vt 0 0", "vn 0 0 1"], "", 1
+        for m in mats:
+            v, f, vb = SU.quad(-1, 1, -1, 1, 0, vb)
+            lines += v
+            body += f"usemtl {m}\n" + "\n".join(x.format(n=1) for x in f) + "\n"
+        # some more geometry around it so that the tree has inner nodes
+        for z in (-2.0, 2.5):
+            v, f, vb = SU.quad(-3, 3, -3, 3, z, vb)
+            lines += v
+            body += "usemtl shiny\n" + "\n".join(x.format(n=1) for x in f) + "\n"
+        SU.write_scene(tmp_path, f"stack{k}", "\n".join(lines) + "\n" + body, SU.MTL_BASIC, lights=[("lamp", (5, 5, 5))])
+        for leaf in (8, 4, 3):
+            s = SU.load(tmp_path, f"stack{k}", leaf_num=leaf)
+            rng = np.random.default_rng(k)
+            n = 400
+            org = np.column_stack([rng.uniform(-0.95, 0.95, n), rng.uniform(-0.95, 0.95, n), np.where(rng.random(n) < 0.5, 1.5, -1.5)]).astype(np.float32)
+            dirs = np.column_stack([np.zeros(n), np.zeros(n), -np.sign(org[:, 2])]).astype(np.float32)
+            t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+            assert np.all(t0 == 1.5)
+            old = H.set_node_kind(1)
+            try:
+                assert H.compressible(s.flat)
+                t1, tri1, uv1, _ = H.trace(s.flat, org, dirs)
+            finally:
+                H.set_node_kind(old)
+            assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1), (mats, leaf)
+            s.close()

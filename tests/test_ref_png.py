@@ -14,17 +14,18 @@ Which snapshot belongs to the committed code was established by ranking all of t
   veach-mis/image10.png   matches parity mode to 1.3 % median block error, correlation 0.9992 (oracle, 4 spp; HIP at 10 spp: 1.05 %, on the
                           two-seed floor of 1.07 %) — and NOT TRT_FLAG_FIXED_NEE (23 %): the three-light bias of Q3 (every CDF draw spans
                           light 1's area), Q4 and Q5 are in the reference's own output, and the restatement reproduces them.
-  staircase/image10.png   parity 7 % at 2 spp, 5.5 % at the snapshot's own 10 spp; fixed-NEE 20 %: same conclusion on six lights and
-                          three textures (texture orientation and the BGR order of pathTracing.cpp:24-25 included).  NOT all of it is
-                          noise: two renders of this estimator with different seeds at 1280x720 x 10 spp differ by 2.2 % (tools/
-                          two_seed_floor.py; veach-mis: floor 1.07 %, snapshot 1.01 % — that one sits ON its floor, mean radiance ratio
-                          1.0000), so ~3 points are systematic: this build renders staircase 7.2 % brighter in the mean (per channel
-                          1.09 / 1.06 / 1.03: the warm lights).  A least-squares fit of the snapshot by six single-light renders gives
-                          leftLight — 72 % of the image's energy, reaching the room through the glass — a weight of 0.88 and the
-                          others 0.92-1.12.  What it is NOT (each a test below): lost updates of the racy accumulation (< 5e-5 of
-                          the mass), the three identically seeded engines (+-1.7 %, the size of the 10-spp floor of the mean), a
-                          missing 1 / P_RR (that variant is 21 % too DARK on staircase).  Unexplained, bounded at 5.6 % median block error.
-  staircase/image256.png  parity 9 %, fixed 22 %: a converged snapshot of the same estimator (same residual: 5.7 % at 256 spp).
+  staircase/image10.png   parity 7 % at 2 spp, 5.6 % at the snapshot's own 10 spp (two-seed floor 2.2 %); fixed-NEE 20 %: the same
+                          conclusion on six lights and three textures (texture orientation and the BGR order of pathTracing.cpp:24-25
+                          included).  The 3.4 points above the floor, the +7.3 % of the mean and its colour (1.09 / 1.06 / 1.03) are
+                          EXPLAINED (round 4, test_staircase_snapshots_weight_specular_bounces_by_ks, profiles/r04_staircase_residual.txt):
+                          the revision that wrote the staircase snapshots weighted a SPECULAR bounce by Ks, the committed source weights
+                          it by the texel Kd (pathTracing.cpp:91-93, Q8).  With that one multiplication switched in the oracle (an explicit
+                          experiment bit) the snapshot is matched ON the floor: mean 0.9999, channels within 0.1 %, 2.3 % median block error;
+                          at 256 spp against image256.png: 0.9997, 0.69 %.  What it is NOT (each a test below): lost updates of the racy
+                          accumulation (< 5e-5 of the mass), the three identically seeded engines (+-1.7 %), a missing 1 / P_RR (21 % too
+                          DARK), a per-light, per-bounce or per-glass-interface factor (fits in the profiles file: none leaves less than 11 %).
+  staircase/image256.png  parity 9 %, fixed 22 %: a converged snapshot of the same revision (5.7 % at 256 spp with the committed weighting,
+                          0.69 % — its noise floor — with Ks).
   veach-mis/image256.png  parity 61 %, fixed 36 %: an older light-selection experiment (its siblings image10-area /
                           -radiance / -avg / -num are named after them); kept as the negative control.
   test/image10.png, test/image10-0.png (`back`)   geometry and pixel grid exact (first/last lit row and column), block
@@ -207,7 +208,7 @@ def test_identically_seeded_engines_do_not_shift_the_brightness(name, w, h):
 def test_staircase_snapshots_have_the_russian_roulette_compensation():
     """... and hypothesis (iii), the one that does explain `back` (next to this test's sibling above): on staircase the estimator WITHOUT
     1 / P_RR is 21 % too dark against image10.png (mean 0.79 of the snapshot's; the committed one 1.07) — the staircase snapshots were
-    written by the committed indirect term, so their 7 % are something else (see the header of this file)."""
+    written with the division, so their 7 % are something else: the weight of SPECULAR bounces (test_staircase_snapshots_weight_specular_bounces_by_ks)."""
     png = _png("staircase_image10.png")
     s = get_scene("staircase", 640, 360)
     p = T.make_params(640, 360, 6, SEEDS["staircase"])
@@ -219,12 +220,45 @@ def test_staircase_snapshots_have_the_russian_roulette_compensation():
     assert r_v <= 0.88, r_v             # measured 0.79
 
 
+def test_staircase_snapshots_weight_specular_bounces_by_ks():
+    """WHAT the staircase residual is (VERDICT r03 task 1; profiles/r04_staircase_residual.txt has the road to it).  pathTracing.cpp:91-93
+    multiplies the light that comes back along a SPECULAR bounce by `Kd` (the texel; quirk Q8) — that is the committed source and what the
+    parity path computes.  The revision that WROTE example-scenes-cg22/staircase/image*.png multiplied it by the material's `Ks` (the
+    `m.Ks = m.Kd` that nextRay still carries at pathTracing.cpp:185 belongs to that weighting).  Three materials of this scene tell the two
+    apart — FloorTiles (Ks 0.2 0.3 0.4 against a texel around 0.5-0.7: Kd returns more light, red most), Metal (Kd 0.2 grey, Ks 0 0.8 0.8: the
+    strip by the door is TEAL in the snapshots and dark grey with Kd), Chrome (equal) — and no other shipped scene does (veach-mis: Kd = Ks on
+    every glossy plate; back: no glossy material), which is why veach-mis sits on its noise floor either way.
+    With ORACLE_MODE_EXPERIMENT_SPECULAR_KS (an explicit oracle mode bit, test infrastructure; never the parity path) at image10.png's own
+    10 spp the whole residual is gone: mean 1.0726 -> 0.9999 of the snapshot's, per channel 1.093 / 1.065 / 1.032 -> 1.000 / 1.000 / 1.000, median
+    block error 5.6 % -> 2.3 % (the two-seed floor of this size is 2.2 %); at 256 spp against image256.png: 1.086 -> 0.9997, 5.7 % -> 0.69 %
+    (full frame, measured once: 12 CPU-minutes).  Here: the lower 420 rows (the floor, the stairs, the strip) at 10 spp."""
+    png = _png("staircase_image10.png")
+    h, w = png.shape[:2]
+    y0 = 300
+    s = get_scene("staircase", w, h)
+    p = T.make_params(w, h, 10, SEEDS["staircase"], tile=(0, y0, w, h))
+    rb = _blocks(_lin8(png[y0:]))
+    teal = (rb[..., 1] > 2.0 * rb[..., 0]) & (rb[..., 2] > 2.0 * rb[..., 0]) & (rb.sum(-1) > 0.05)  # the Metal strip as the snapshot shows it
+    assert teal.sum() >= 1
+    out = {}
+    for name, mode in (("committed", O.MODE_ITERATIVE), ("ks", O.MODE_ITERATIVE | O.MODE_EXPERIMENT_SPECULAR_KS)):
+        ob = _blocks(_lin8(T.tonemap(O.render(s.flat, p, mode=mode)[0])))
+        ch = ob.mean((0, 1)) / rb.mean((0, 1))
+        out[name] = (float(ob.mean() / rb.mean()), float(ch.max() / ch.min()), float(np.median(np.abs(ob - rb) / (0.02 + rb))), ob[teal].mean(0))
+    (r_c, spread_c, med_c, teal_c), (r_k, spread_k, med_k, teal_k) = out["committed"], out["ks"]
+    assert abs(r_k - 1.0) <= 0.01 and spread_k <= 1.01 and med_k <= 0.03, out["ks"]          # measured (full frame) 0.9999, 1.0007, 0.0233
+    assert r_c >= 1.05 and spread_c >= 1.035 and med_c >= 1.8 * med_k, out["committed"]      # measured (full frame) 1.0726, 1.0588, 0.0564
+    assert teal_k[1] > 3.0 * teal_k[0] and teal_k[2] > 1.5 * teal_k[0]                         # teal, as in the snapshot (0.037, 0.180, 0.080)
+    assert teal_c[0] > teal_c[1] > teal_c[2]                                                   # the committed weighting: dim and warm
+
+
 # ------------------------------------------------------------------------------------------------ HIP path
 # fixture -> (samples per pixel of the snapshot = what the HIP render uses, max median block error, max p90, min correlation)
 GPU_BOUNDS = {
     "veach-mis_image10.png": (10, 0.02, 0.07, 0.998),      # measured 0.0105, 0.045, 0.9994
-    "staircase_image10.png": (10, 0.065, 0.25, 0.975),     # measured 0.055, 0.194, 0.985: a two-seed floor of 0.022 + 0.033 systematic (file header)
-    "staircase_image256.png": (256, 0.065, 0.25, 0.975),   # measured 0.057, 0.199, 0.987: the same residual, converged
+    # staircase: the committed estimator against snapshots of the Ks-weighting revision (file header): floor + the explained bias
+    "staircase_image10.png": (10, 0.065, 0.25, 0.975),     # measured 0.055, 0.194, 0.985: a two-seed floor of 0.022 + 0.034 from Kd-for-Ks on the floor tiles
+    "staircase_image256.png": (256, 0.065, 0.25, 0.975),   # measured 0.057, 0.199, 0.987: floor 0.007 + the same bias, converged
 }
 
 

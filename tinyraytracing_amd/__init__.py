@@ -64,9 +64,10 @@ class Scene:
         return cls(h)
 
     @classmethod
-    def named(cls, name, width=0, height=0, leaf_num=None, builder="auto", n=None, seed=None):
+    def named(cls, name, width=0, height=0, leaf_num=None, builder="auto", n=None, seed=None, device=0):
         """Shipped and synthetic scenes: back, veach-mis, staircase, soup (n random triangles in
-        the back box, BASELINE config 3), blob (displaced geodesic sphere, config 5)."""
+        the back box, BASELINE config 3), blob (displaced geodesic sphere, config 5).  `device`: where builder="lbvh" runs
+        (a rank of a multi-GPU job passes its own GPU; the host builders ignore it)."""
         if name in ("back", "veach-mis", "staircase"):
             d = os.path.join(SCENES_DIR, name)
             s = cls.load(os.path.join(d, name + ".xml"), os.path.join(d, name + ".obj"), os.path.join(d, name + ".mtl"), d, width, height)
@@ -84,7 +85,7 @@ class Scene:
             # tiny scenes are walked wave-uniformly (every node, every triangle: trt_kernels.h IMPL 0), where fewer,
             # fuller leaves are cheaper; everything else is traversed per ray, where 2 measured best
             leaf_num = default_leaf(name, s.info["n_triangles"])
-        s.build_bvh(leaf_num, builder)
+        s.build_bvh(leaf_num, builder, device)
         return s
 
     def _check(self, rc):

@@ -462,15 +462,15 @@ int buildSceneImage(const trt_scene* s, SceneImage& im)
         if (std::atoi(e) == 0) im.light_boxes.assign(s->n_lights, LightBox{{-3.0e38f, -3.0e38f, -3.0e38f}, {3.0e38f, 3.0e38f, 3.0e38f}});
     im.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
     lap("leaf boxes, light boxes");
-    // The 8-wide compressed nodes (trt_oct.h) for the persistent traversal kernels, when the tree qualifies (nested, finite, leaves
-    // of <= 3 triangles): TRT_NODE_KIND=0/1 in the environment forces either kind (A/B runs, tests).
+    // The 8-wide compressed nodes (trt_oct.h) for the persistent traversal kernels, when the tree qualifies (nested, finite; larger
+    // leaves are laid out as several slots with the leaf's own box): TRT_NODE_KIND=0/1 in the environment forces either kind (A/B runs, tests).
     bool want_oct = im.trace_impl != 0 && TRT_DEFAULT_NODE_KIND == 1;
     if (const char* e = std::getenv("TRT_NODE_KIND")) want_oct = im.trace_impl != 0 && std::atoi(e) == 1;
     if (want_oct) {
         im.oct = buildOct(s->nodes, s->n_nodes, s->n_tris, im.isect.data(), im.threads);
         im.node_kind = im.oct.ok ? 1 : 0;
         lap("8-wide collapse");
-        if (im.dbg) std::fprintf(stderr, "trt_create: oct tree %s (%s): %zu nodes, %u levels\n", im.oct.ok ? "built" : "not built", im.oct.why, im.oct.nodes.size(), im.oct.levels);
+        if (im.dbg) std::fprintf(stderr, "trt_create: oct tree %s (%s): %zu nodes, %u levels, %u leaves of more than 3 triangles split\n", im.oct.ok ? "built" : "not built", im.oct.why, im.oct.nodes.size(), im.oct.levels, im.oct.split_leaves);
     }
     if (im.dbg) std::fprintf(stderr, "trt_create: %zu wide nodes, node kind %d, stack need %u, %u host threads\n", im.wide.nodes.size(), im.node_kind, im.wide.stack_need, im.threads);
 
@@ -526,6 +526,11 @@ int createOnDevice(const SceneImage& im, int device, trt_handle** out)
         unsigned a = 0, b = 0;
         if (std::sscanf(e, "%u:%u", &a, &b) == 2 && a > 0 && b > 0 && a < 1024 && b < 1024) { h->sc.sched_in_w = a; h->sc.sched_lf_w = b; }
     }
+    // leaf steps of the oct driver: two triangles each on trees with leaves of <= 3; a tree whose leaves were split into several slots
+    // (the reference's leaf size 8) brings up to 24 triangles per node, all of which have to be tested: four per step there
+    // (profiles/r04_leaf8.txt has the sweep)
+    h->sc.leaf_loop = im.oct.split_leaves * 8u > s->n_tris / 8u ? 4u : 2u;  // at least an eighth of the triangles in such leaves (8 per leaf assumed)
+    if (const char* e = std::getenv("TRT_LEAF_LOOP")) h->sc.leaf_loop = std::min(24u, std::max(1u, (uint32_t)std::strtoul(e, nullptr, 10)));
     if (const char* e = std::getenv("TRT_REFILL_MIN")) h->sc.refill_min = std::min(64u, std::max(1u, (uint32_t)std::strtoul(e, nullptr, 10)));
     if (im.dbg) std::fprintf(stderr, "trt_create: refill_min %u tail_n %u\n", h->sc.refill_min, h->tail_n);
     if (const char* e = std::getenv("TRT_TRACE_RPW")) h->rays_per_wave = (uint32_t)std::strtoul(e, nullptr, 10);

@@ -531,14 +531,12 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
 // slower: the ray fetch and its three reciprocals then run in almost every node step for a handful of lanes.  These kernels are bound
 // by VALU ISSUE (profiles/r03_roofs_stair_oct.txt): what counts is wave-level instructions per ray, and a refill batch of 48 amortises
 // 200 of them over 48 rays.  profiles/r03_ab_oct.txt has all of it.  Static slices and batches stay.)
-// TRT_OCT_LEAF_LOOP: triangles a lane tests per leaf step.  Leaves hold two: with 2 the second one follows at once, without another
-// round of votes, and the lane is back at a node with its neighbours (lanes per leaf step 0.45 -> 0.88; staircase, veach-mis +4 %,
-// the meshes +2-3 %; 3: no better).
+// sc.leaf_loop (TRT_OCT_LEAF_LOOP as a scene parameter since round 4): triangles a lane tests per leaf step.  Leaves hold two: with 2 the
+// second one follows at once, without another round of votes, and the lane is back at a node with its neighbours (lanes per leaf step
+// 0.45 -> 0.88; staircase, veach-mis +4 %, the meshes +2-3 %; 3: no better).  A caller's tree with larger leaves (the reference's: 8)
+// brings a group of up to 24 triangles per node and gets a longer loop (trt_create; TRT_LEAF_LOOP in the environment overrides).
 // (Also measured: the root and its children read from an LDS copy — a fifth of all node fetches on veach-mis —: +-0.3 %.  These kernels
 // are bound by VALU issue, profiles/r03_roofs_stair.txt, not by the texture addresser.  Removed.)
-#ifndef TRT_OCT_LEAF_LOOP
-#define TRT_OCT_LEAF_LOOP 2
-#endif
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, bool PRIMARY>
 __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
                                            const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, uint32_t* __restrict__ spill,
@@ -632,9 +630,9 @@ __device__ __forceinline__ void traceQueuePersistentOct(const SceneDev& sc, cons
             }
         } else {
             if (is_leaf) {
-                // up to TRT_OCT_LEAF_LOOP triangles of the lane's group per step
+                // up to sc.leaf_loop triangles of the lane's group per step
 #pragma unroll 1
-                for (int rep = 0; rep < TRT_OCT_LEAF_LOOP && tg.y != 0u; ++rep) {
+                for (uint32_t rep = 0; (rep == 0u || rep < sc.leaf_loop) && tg.y != 0u; ++rep) {  // at least one: a step always makes progress
                     const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
                     tg.y &= tg.y - 1u;
                     const TriIsect T = sc.tri_trav[tg.x + b];

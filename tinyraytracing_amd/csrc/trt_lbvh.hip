@@ -587,6 +587,9 @@ int trt_build_lbvh(const float* tri_v, uint32_t n_tris, int leaf_num, int device
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(TRT_ENODEV, "no HIP device");
     if (device < 0 || device >= ndev) return fail(TRT_ENODEV, "device ordinal out of range");
+    // the caller's current device comes back on every exit path (declared first: restored after the buffers and events below are released)
+    struct DeviceGuard { int prev = -1; ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); } } dev_guard;
+    if (hipGetDevice(&dev_guard.prev) != hipSuccess) dev_guard.prev = -1;
     HIPC(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPC(hipGetDeviceProperties(&prop, device));

@@ -10,7 +10,7 @@
 //   q2 = (qlo.x[0..3], qlo.x[4..7], qlo.y[0..3], qlo.y[4..7])              one byte per child and bound:
 //   q3 = (qlo.z[0..3], qlo.z[4..7], qhi.x[0..3], qhi.x[4..7])                  bound = p + q * 2^(e-127)
 //   q4 = (qhi.y[0..3], qhi.y[4..7], qhi.z[0..3], qhi.z[4..7])
-//   meta[i]: 0 = empty slot; inner child: 0b001sssss with sssss = 24 + i; leaf: (unary triangle count, 1..3 bits) << 5 | offset of
+//   meta[i]: 0 = empty slot; inner child: 0b001sssss with sssss = 24 + i; leaf slot: (unary triangle count, 1..3 bits) << 5 | offset of
 //   its first triangle from tri_base (0..23).  The low five bits are the child's position in the 32-bit hit mask of a visit: bits
 //   24..31 inner children (xor-ed with the ray's octant so that the highest set bit is the child to enter first), bits 0..23 one
 //   bit per triangle.
@@ -162,17 +162,23 @@ TRT_HD inline uint32_t octNextChild(OctGroup& ng, const OctRay& R)
     return ng.x + rel;
 }
 
-// Triangle record of the oct traversal: TriIsect with c.w = original (post-BVH) index | position in its leaf << 27 | triangles in
-// that leaf << 29 (leaves of at most 3 triangles).  tri_trav holds every node's leaf triangles next to each other, each leaf's
-// in index order.
+// Triangle record of the oct traversal: TriIsect with c.w = original (post-BVH) index | position in the CALLER's leaf << 27 (0..14) and
+// the size of that leaf (1..15) in bits 1..4 of the flags word c.z (bits the other users of the flags — emissive bit 0, material
+// bits 8.. — do not read).  tri_trav holds every node's leaf triangles next to each other, each slot's in index order.  A caller's leaf
+// of 4..15 triangles (the reference builds with 8, main.cpp:76) is laid out as several slots of <= 3 triangles (trt_oct_build.h), so
+// position and size speak of the caller's leaf, not of the slot: the tie rule below needs to know the reference's leaf.
 TRT_HD inline uint32_t octTriOrig(uint32_t w) { return w & 0x07FFFFFFu; }
-TRT_HD inline uint32_t octTriPos(uint32_t w) { return (w >> 27) & 3u; }
-TRT_HD inline uint32_t octTriCount(uint32_t w) { return w >> 29; }
+TRT_HD inline uint32_t octTriPos(uint32_t w) { return (w >> 27) & 15u; }
+TRT_HD inline uint32_t octTriCount(uint32_t fl) { return (fl >> 1) & 15u; }
 
 // Fold of one triangle candidate into the best hit: interactBVHNode's scan (bvh.cpp:219) and traverseBVH's merge
-// (bvh.cpp:168-172) in one step per candidate — nearer wins; at equal distance a candidate of the SAME leaf as the best
-// (candidates of a leaf arrive in index order) wins iff it is emissive, one of another leaf by "leftmost emissive, else
-// rightmost" (the order-independent form of the sibling merge; the same fold as uniformWalk()'s, trt_kernels.h).
+// (bvh.cpp:168-172) in one step per candidate, in a form that does not depend on the order the candidates arrive in (the slots of
+// one caller's leaf are entered in octant order, not index order).  Nearer wins.  At equal distance the reference's scan of a leaf
+// keeps the FIRST candidate unless a later one is emissive, and then the LAST emissive one; its merge of siblings keeps the
+// leftmost leaf whose result is emissive, else the rightmost leaf's.  As one total order of preference: emissive before not;
+// among emissive ones the leftmost leaf, inside a leaf the highest index; among the others the rightmost leaf, inside a leaf the
+// lowest index.  Leaves cover disjoint index ranges in tree order, so "left of" is "index below" (the same fold as
+// uniformWalk()'s, trt_kernels.h, which sees whole leaves).
 TRT_HD inline void octFold(float t, uint32_t w, uint32_t fl, float& best_t, int32_t& best_tri, uint32_t& best_flags)
 {
     const int32_t j = (int32_t)octTriOrig(w);
@@ -180,8 +186,9 @@ TRT_HD inline void octFold(float t, uint32_t w, uint32_t fl, float& best_t, int3
     if (t == best_t && best_tri >= 0) {
         const bool em = (fl & 1u) != 0, bem = (best_flags & 1u) != 0;
         const int32_t first = j - (int32_t)octTriPos(w);
-        const bool same_leaf = best_tri >= first && best_tri < first + (int32_t)octTriCount(w);
-        take = same_leaf ? em : (em ? (!bem || j < best_tri) : (!bem && j > best_tri));
+        const bool same_leaf = best_tri >= first && best_tri < first + (int32_t)octTriCount(fl);
+        const bool below = j < best_tri;
+        take = em ? (!bem || (below != same_leaf)) : (!bem && (below == same_leaf));
     }
     if (take) { best_t = t; best_tri = j; best_flags = fl; }
 }

@@ -4,6 +4,13 @@
 // Collapse: the dynamic programme of trt_wide.h for eight children — which intermediate boxes to drop so that the sum of the
 // half-areas of all wide nodes (the expected number of node visits) is minimal.  Dropping boxes cannot change a hit (trt_wide.h);
 // this node kind is only built for NESTED trees with finite boxes (every other tree keeps the exact 4-wide nodes).
+// Leaves: a slot holds <= 3 triangles.  A caller's leaf of 4..15 triangles — the reference's own trees have up to 8 (main.cpp:76,
+// bvh.cpp:16-144) — is laid out as ceil(count / 3) slots over consecutive pieces of its range, EVERY ONE WITH THE LEAF'S OWN BOX
+// (splitLargeLeaves): the reference tests every triangle of a leaf whose box the ray passes (bvh.cpp:151-154, 211-229), and a
+// tighter box around a piece could skip a triangle whose Moller-Trumbore test would have accepted the ray — for a ray nearly in
+// the triangle's plane the computed distance tn / det can lie anywhere along the ray, so no box smaller than the
+// leaf's is safe.  With the leaf's box on every piece the visited set of triangles is exactly that of the caller's tree; the tie
+// rule (octFold) and the check of the result (leaf_box) speak of the caller's leaf throughout.
 // Slots: a child's slot index says on which side of the node's centre it lies (bit 2 = +x, bit 1 = +y, bit 0 = +z), assigned
 // greedily by the projection of its centre on the slot's diagonal, so that "slot xor (7 - ray octant), highest first" enters the
 // children roughly front to back without sorting (Ylitie et al. 2017).  The order is free: only the visited SET matters.
@@ -26,20 +33,83 @@ namespace trtd {
 
 struct OctTree {
     std::vector<OctNode> nodes;     // nodes[0] is the root
-    std::vector<TriIsect> tri_trav; // the triangles in node order: c.w = original index | position in leaf << 27 | leaf size << 29
+    std::vector<TriIsect> tri_trav; // the triangles in node order: c.w = original index | position in the caller's leaf << 27, c.z |= that leaf's size << 1
     uint32_t levels = 0;            // nodes on the longest root path: the traversal stack needs levels - 1 entries
-    bool ok = false;                // false: this tree keeps the exact 4-wide nodes (not nested / not finite / a leaf of more than 3 triangles / coordinates >= 2^40)
+    bool ok = false;                // false: this tree keeps the exact 4-wide nodes (not nested / not finite / coordinates >= 2^40)
+    uint32_t split_leaves = 0;      // caller's leaves of more than 3 triangles that were laid out as several slots
     const char* why = "";
 };
 
+// The caller's tree with every leaf of more than TRT_OCT_MAX_LEAF_TRIS triangles replaced by a balanced binary subtree over
+// consecutive pieces of <= TRT_OCT_MAX_LEAF_TRIS triangles of its range, every box in that subtree the leaf's own (header).  New
+// nodes are appended, so parents still precede children.  Empty result: nothing to split.
+inline std::vector<trt_bvh_node> splitLargeLeaves(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t* n_split)
+{
+    std::vector<trt_bvh_node> out;
+    *n_split = 0;
+    bool any = false;
+    for (uint32_t n = 0; n < n_nodes2 && !any; ++n)
+        for (uint32_t ref : {nodes2[n].child0, nodes2[n].child1})
+            if ((ref & TRT_LEAF_BIT) && TRT_LEAF_COUNT(ref) > TRT_OCT_MAX_LEAF_TRIS) any = true;
+    if (!any) return out;
+    out.assign(nodes2, nodes2 + n_nodes2);
+    struct Piece { uint32_t first, count; };
+    for (uint32_t n = 0; n < n_nodes2; ++n) {
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t ref = k ? nodes2[n].child1 : nodes2[n].child0;
+            if (!(ref & TRT_LEAF_BIT) || TRT_LEAF_COUNT(ref) <= TRT_OCT_MAX_LEAF_TRIS) continue;
+            ++*n_split;
+            const float* lo = k ? nodes2[n].lo1 : nodes2[n].lo0;
+            const float* hi = k ? nodes2[n].hi1 : nodes2[n].hi0;
+            const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
+            const uint32_t m = (count + TRT_OCT_MAX_LEAF_TRIS - 1u) / TRT_OCT_MAX_LEAF_TRIS;  // 2..5 pieces, sizes as even as possible
+            Piece pc[5];
+            for (uint32_t i = 0, at = first; i < m; ++i) { pc[i].first = at; pc[i].count = count / m + (i < count % m ? 1u : 0u); at += pc[i].count; }
+            // balanced subtree over pieces [a, b): returns its reference
+            struct Rec {
+                std::vector<trt_bvh_node>& out; const Piece* pc; const float* lo; const float* hi;
+                uint32_t make(uint32_t a, uint32_t b)
+                {
+                    if (b - a == 1) return TRT_MAKE_LEAF(pc[a].first, pc[a].count);
+                    const uint32_t me = (uint32_t)out.size();
+                    out.emplace_back();
+                    const uint32_t mid = a + (b - a + 1) / 2;
+                    const uint32_t c0 = make(a, mid), c1 = make(mid, b);
+                    trt_bvh_node& nd = out[me];
+                    for (int x = 0; x < 3; ++x) { nd.lo0[x] = nd.lo1[x] = lo[x]; nd.hi0[x] = nd.hi1[x] = hi[x]; }
+                    nd.child0 = c0; nd.child1 = c1;
+                    nd.reserved[0] = nd.reserved[1] = 0u;
+                    return me;
+                }
+            } rec{out, pc, lo, hi};
+            const uint32_t sub = rec.make(0, m);
+            if (k) out[n].child1 = sub; else out[n].child0 = sub;
+        }
+    }
+    return out;
+}
+
 // `threads`: host threads to use (trt_wide.h, par); the tree does not depend on it.
-inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t n_tris, const TriIsect* tri_isect, unsigned threads = 1)
+inline OctTree buildOct(const trt_bvh_node* caller_nodes2, uint32_t caller_n_nodes2, uint32_t n_tris, const TriIsect* tri_isect, unsigned threads = 1)
 {
     using namespace wide_detail;
     constexpr int W = 8;
     OctTree t;
-    if (n_nodes2 == 0) { t.why = "no nodes"; return t; }
-    // ---- premises: finite boxes with lo <= hi below 2^40, nested, leaves of <= 3 triangles
+    if (caller_n_nodes2 == 0) { t.why = "no nodes"; return t; }
+    // position and size of every triangle's leaf IN THE CALLER'S TREE (the reference's leaf: tie rule, octFold)
+    std::vector<uint8_t> leaf_info((size_t)std::max<uint32_t>(n_tris, 1u), 0);  // pos | count << 4
+    par::forRange(caller_n_nodes2, threads, 65536, [&](size_t n0, size_t n1) {
+        for (size_t n = n0; n < n1; ++n)
+            for (uint32_t ref : {caller_nodes2[n].child0, caller_nodes2[n].child1}) {
+                if (!(ref & TRT_LEAF_BIT)) continue;
+                const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
+                for (uint32_t i = 0; i < count && first + i < n_tris; ++i) leaf_info[first + i] = (uint8_t)(i | (count << 4));
+            }
+    });
+    const std::vector<trt_bvh_node> split = splitLargeLeaves(caller_nodes2, caller_n_nodes2, &t.split_leaves);
+    const trt_bvh_node* nodes2 = split.empty() ? caller_nodes2 : split.data();
+    const uint32_t n_nodes2 = split.empty() ? caller_n_nodes2 : (uint32_t)split.size();
+    // ---- premises: finite boxes with lo <= hi below 2^40, nested (leaves hold <= 3 triangles after splitLargeLeaves)
     {
         struct Bad { uint32_t node; const char* why; };
         const unsigned T = threads ? threads : 1;
@@ -290,7 +360,9 @@ inline OctTree buildOct(const trt_bvh_node* nodes2, uint32_t n_nodes2, uint32_t 
                         const uint32_t first = TRT_LEAF_FIRST(ref), count = TRT_LEAF_COUNT(ref);
                         for (uint32_t i = 0; i < count; ++i) {
                             TriIsect T = tri_isect[first + i];
-                            T.c.w = u2f((first + i) | (i << 27) | (count << 29));
+                            const uint32_t li = leaf_info[first + i];  // the caller's leaf, not this slot
+                            T.c.w = u2f((first + i) | ((li & 15u) << 27));
+                            T.c.z = u2f(f2u(T.c.z) | ((li >> 4) << 1));
                             t.tri_trav[ti++] = T;
                         }
                     } else {

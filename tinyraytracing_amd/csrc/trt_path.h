@@ -143,6 +143,7 @@ struct SceneDev {
     uint32_t n_tris, n_nodes, n_wnodes, n_onodes, n_lights;
     uint32_t refill_min;  // persistent traversal drivers: lanes to have free before a refill (trt_kernels.h)
     uint32_t sched_in_w, sched_lf_w;  // scheduler driver: node step iff sched_in_w * (lanes at nodes) >= sched_lf_w * (lanes at leaves)
+    uint32_t leaf_loop;   // oct driver: triangles a lane tests per leaf step (trt_kernels.h; 2 for trees with leaves of <= 3, more where the caller's leaves are larger)
     float light0_area;  // Q3: every light's CDF draw spans lights[0].area (pathTracing.cpp:38)
     float leaf_alpha;   // absolute part of the leaf-box rule's tolerance (trt_leaf_floor, trt_prims.h): sceneLeafAlpha()
     trt_camera cam;

@@ -64,24 +64,59 @@ def _row_indices(width, height, world, row_block, device):
     return _row_index_cache[key]
 
 
-def render_distributed(render_fn, width, height, spp, seed, dist=None, device=None, row_block=ROW_BLOCK, **kw):
+class StepTimes:
+    """Where one rank's step goes (bench.py --gpus N): marks before the render, after it, and after the gather + un-interleave.
+    Device tensors with RCCL: torch.cuda events on the current stream, read after the timed region (no host wait inside it);
+    otherwise (gloo rehearsals, CPU tests) the host clock."""
+
+    def __init__(self):
+        self.marks = []  # per step: three events or three floats
+
+    def mark(self, use_events):
+        import time
+        import torch
+        if use_events:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        return time.perf_counter()
+
+    def totals_ms(self):
+        """(render ms, gather ms) summed over the recorded steps; call after a synchronize."""
+        r = g = 0.0
+        for a, b, c in self.marks:
+            if isinstance(a, float):
+                r += (b - a) * 1e3
+                g += (c - b) * 1e3
+            else:
+                r += a.elapsed_time(b)
+                g += b.elapsed_time(c)
+        return r, g
+
+
+def render_distributed(render_fn, width, height, spp, seed, dist=None, device=None, row_block=ROW_BLOCK, times=None, **kw):
     """Renders this rank's stripes with `render_fn(params) -> (array-or-tensor [rows, width, 3], stats)`
     and gathers them on rank 0.  Returns (image tensor [height, width, 3] on rank 0 else None, stats of
     this rank).  The image stays where the gather ran: on the GPU with RCCL (`device` given, backend
     nccl), on the CPU with gloo.  With more than one rank the returned tensor is rank 0's landing buffer and is
     overwritten by the next call: clone it to keep it.
 
-    `dist` is torch.distributed (already initialised) or None for a single process."""
+    `dist` is torch.distributed (already initialised) or None for a single process.  `times`: a StepTimes that gets this step's marks."""
     import torch
 
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     p = shard_params(width, height, spp, seed, rank, world, row_block, **kw)
+    use_events = times is not None and device is not None and str(device).startswith("cuda") and (dist is None or dist.get_backend() == "nccl")
+    m0 = times.mark(use_events) if times is not None else None
     out, stats = render_fn(p)
     t = out if torch.is_tensor(out) else torch.from_numpy(np.ascontiguousarray(out))
     if device is not None:
         t = t.to(device)
+    m1 = times.mark(use_events) if times is not None else None
     if world == 1:
+        if times is not None:
+            times.marks.append((m0, m1, m1))
         return t.reshape(height, width, 3), stats
     pad_rows = max_rows(width, height, world, row_block)
     nrows = t.numel() // (width * 3)
@@ -102,8 +137,12 @@ def render_distributed(render_fn, width, height, spp, seed, dist=None, device=No
         gather_list = _gather_cache[key][0]
     dist.gather(buf, gather_list, dst=0)  # the single collective of the data path
     if rank != 0:
+        if times is not None:
+            times.marks.append((m0, m1, times.mark(use_events)))
         return None, stats
     img = _gather_cache[key][1]
     for r, idx in enumerate(_row_indices(width, height, world, row_block, buf.device)):
         img.index_copy_(0, idx, gather_list[r][: idx.numel()])
+    if times is not None:
+        times.marks.append((m0, m1, times.mark(use_events)))
     return img, stats

@@ -2,10 +2,13 @@
 
 #include "trt_build.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 namespace trt {
@@ -92,8 +95,28 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
         std::vector<uint32_t> order(std::max<size_t>(n, 1));
         uint32_t n_nodes = 0;
         const int dev = opts.devices.empty() ? opts.device : opts.devices[0];
-        if (trt_build_lbvh(v.data(), (uint32_t)n, opts.leaf_num, dev, bvh.nodes.data(), (uint32_t)bvh.nodes.size(), &n_nodes, order.data(), &bvh.depth, nullptr) != TRT_OK)
-            throw std::runtime_error(std::string("trt_build_lbvh: ") + trt_build_last_error());
+        // libtrt_lbvh.so is loaded here, on request, and nowhere else: a render with the host builder neither needs nor maps it
+        // (include/trt_build.h).  Looked up next to this executable / library first (the in-tree layout), then on the loader's path.
+        using build_fn = decltype(&trt_build_lbvh);
+        using err_fn = decltype(&trt_build_last_error);
+        static void* lib = nullptr;
+        if (!lib) {
+            Dl_info me{};
+            std::string dir;
+            if (dladdr(reinterpret_cast<void*>(&sceneHash), &me) && me.dli_fname) {
+                dir = me.dli_fname;
+                const size_t slash = dir.find_last_of('/');
+                dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+            }
+            if (!dir.empty()) lib = dlopen((dir + "libtrt_lbvh.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!lib) lib = dlopen("libtrt_lbvh.so", RTLD_NOW | RTLD_LOCAL);
+            if (!lib) throw std::runtime_error(std::string("the GPU BVH builder was asked for but libtrt_lbvh.so does not load: ") + dlerror());
+        }
+        const build_fn build = reinterpret_cast<build_fn>(dlsym(lib, "trt_build_lbvh"));
+        const err_fn last_error = reinterpret_cast<err_fn>(dlsym(lib, "trt_build_last_error"));
+        if (!build || !last_error) throw std::runtime_error("libtrt_lbvh.so lacks trt_build_lbvh / trt_build_last_error");
+        if (build(v.data(), (uint32_t)n, opts.leaf_num, dev, bvh.nodes.data(), (uint32_t)bvh.nodes.size(), &n_nodes, order.data(), &bvh.depth, nullptr) != TRT_OK)
+            throw std::runtime_error(std::string("trt_build_lbvh: ") + last_error());
         bvh.nodes.resize(n_nodes);
         gpu_order.swap(order);  // the flat arrays are gathered through it below: position i = scene.triangles[order[i]]
     } else {

@@ -4,6 +4,8 @@
 16x16... block means as a non-negative-free least-squares combination of the six block images, on the blocks that stay clear of the
 8-bit clamp.  A weight of 1 says "this light's light arrives as in the reference".  CPU only (the fast oracle).
 Round 3: weights 1.71, 1.71 (two lights of negligible energy), 1.12, 0.88 (leftLight: 72 % of the energy), 0.97, 0.92.
+Round 4: superseded by tools/staircase_decomp.py + tools/staircase_fit.py (full resolution, 256 spp, bootstrap intervals) — no per-light factor explains
+the snapshot; the weight of SPECULAR bounces does (profiles/r04_staircase_residual.txt).
 usage: tools/per_light_fit.py [spp]"""
 import os
 import sys
