@@ -112,7 +112,7 @@ extern "C" int hostsim_set_node_kind(int nk)
     g_node_kind = nk;
     return old;
 }
-// 1 when `s` can be walked with the compressed 8-wide nodes (nested, finite boxes, leaves of <= 3 triangles)
+// 1 when `s` can be walked with the compressed 8-wide nodes (nested, finite boxes; leaves of more than 3 triangles are split into slots)
 extern "C" int hostsim_compressible(const trt_scene* s)
 {
     std::vector<TriIsect> isect(s->n_tris);

@@ -91,6 +91,7 @@ struct trt_handle {
     uint32_t depth = 0;       // stack entries a traversal can need (wide tree), + 1
     uint32_t bvh2_depth = 0;  // depth of the caller's BVH2
     uint32_t shade_tabs = 0;  // which k_shade<TABS> this scene runs
+    uint32_t shade_pad_lds = 0;  // TRT_SHADE_PAD_LDS (probe): dynamic LDS bytes added to every k_shade launch — takes blocks off the CU to measure how the kernel's time hangs on its occupancy
     const void* lds_image = nullptr;  // the tables of shade_tabs, packed
     uint32_t lds_image_bytes = 0;
     uint32_t lds_tab[5] = {0, 0, 0, 0, 0};  // bytes of materials / lights / light CDF / light triangles / (tiny scenes) shading triangles that k_shade stages in LDS
@@ -620,6 +621,15 @@ int createOnDevice(const SceneImage& im, int device, trt_handle** out)
     std::memset(h->pinned_counts, 0, 2 * (2 * COUNT_ROW + 16) * sizeof(uint32_t));  // sequence words start at 0; the first one asked for is 1
     if (const char* e = std::getenv("TRT_SLOTS")) h->n_slots = std::atoi(e) >= 2 ? 2 : 1;
     if (const char* e = std::getenv("TRT_TEST_FAIL_AT_BOUNCE")) h->fail_at_bounce = std::atoi(e);
+    if (const char* e = std::getenv("TRT_SHADE_PAD_LDS")) {
+        h->shade_pad_lds = std::min(100000u, (uint32_t)std::strtoul(e, nullptr, 10));
+        // more than 64 KiB per block needs the opt-in; a refusal shows as a launch error, not as a silent no-op
+#define TRT_PAD_ATTR(T) \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->shade_pad_lds); \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->shade_pad_lds);
+        TRT_PAD_ATTR(31u) TRT_PAD_ATTR(15u) TRT_PAD_ATTR(7u) TRT_PAD_ATTR(3u) TRT_PAD_ATTR(0u)
+#undef TRT_PAD_ATTR
+    }
 
     *out = h.release();
     return TRT_OK;
@@ -879,18 +889,24 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
         A.lds_tshade_bytes = h->lds_tab[4];
         A.lds_image = (const f4*)h->lds_image;
         A.lds_image_words = h->lds_image_bytes / 16u;
-        A.rows_lds = (rows.size() <= TRT_SHADE_ROWS_LDS && p->height <= 65536) ? (uint32_t)rows.size() : 0u;
+        const bool one_light = nl == 1u;  // k_shade's two flavours (trt_kernels.h): 512-thread blocks at 6 waves per SIMD, or 256-thread blocks at 5
+        const uint32_t shade_block = one_light ? (uint32_t)TRT_SHADE1_BLOCK : (uint32_t)TRT_SHADEN_BLOCK;
+        A.rows_lds = (rows.size() <= shadeRowsLds((int)shade_block) && p->height <= 65536) ? (uint32_t)rows.size() : 0u;
         A.stats = d_stats;
         tm.begin(TRT_K_SHADE, S.stream);
         {
-            const dim3 grid(std::min<uint32_t>((S.n_active + TRT_SHADE_BLOCK - 1) / TRT_SHADE_BLOCK, 65536u));
+            const dim3 grid(std::min<uint32_t>((S.n_active + shade_block - 1) / shade_block, 65536u)), blk(shade_block);
+#define TRT_LAUNCH_SHADE(T) \
+            if (one_light) hipLaunchKernelGGL((k_shade<T, true>), grid, blk, h->shade_pad_lds, S.stream, h->sc, A); \
+            else hipLaunchKernelGGL((k_shade<T, false>), grid, blk, h->shade_pad_lds, S.stream, h->sc, A);
             switch (h->shade_tabs) {
-                case 31u: hipLaunchKernelGGL(k_shade<31u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
-                case 15u: hipLaunchKernelGGL(k_shade<15u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
-                case 7u: hipLaunchKernelGGL(k_shade<7u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
-                case 3u: hipLaunchKernelGGL(k_shade<3u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
-                default: hipLaunchKernelGGL(k_shade<0u>, grid, dim3(TRT_SHADE_BLOCK), 0, S.stream, h->sc, A); break;
+                case 31u: TRT_LAUNCH_SHADE(31u) break;
+                case 15u: TRT_LAUNCH_SHADE(15u) break;
+                case 7u: TRT_LAUNCH_SHADE(7u) break;
+                case 3u: TRT_LAUNCH_SHADE(3u) break;
+                default: TRT_LAUNCH_SHADE(0u) break;
             }
+#undef TRT_LAUNCH_SHADE
         }
         tm.end(S.stream);
         st.launches[TRT_K_SHADE]++;

@@ -42,21 +42,29 @@ constexpr int TRT_TRACE_BLOCK = 256;
 #define TRT_LDS_STACK_MAX_LEVELS 16
 #endif
 constexpr int TRT_LDS_STACK_MAX = TRT_LDS_STACK_MAX_LEVELS;   // deepest LDS stack (x 256 lanes x 4 B per block); deeper levels spill to global
-#ifndef TRT_SHADE_BLOCK_THREADS
-#define TRT_SHADE_BLOCK_THREADS 512
+// k_shade comes in two flavours, chosen by the scene's light count (round 4; profiles/r04_ab_shade_tail.txt).  The kernel waits on memory at low
+// occupancy (one block per CU instead of two: 1.67x its time), and a CU takes whole blocks whose waves divide evenly over its 4 SIMDs:
+//   ONE light (back, soup, blob: nl known at compile time, no per-light stage pipeline): 80 VGPRs without scratch -> 512-thread blocks, THREE per CU
+//     = 6 waves per SIMD (was 108 VGPRs, 2 blocks, 4 waves): k_shade -13 % on `back`, -14 % on the 10 M mesh;
+//   SEVERAL lights: 96 VGPRs without scratch -> 256-thread blocks, FIVE per CU = 5 waves per SIMD, and five independently phased blocks
+//     per SIMD instead of two: -14 % on veach-mis, -10 % on staircase.  (256-thread blocks with one light LOSE 60 %: twice the queue
+//     reservations on ONE counter — same-address atomics serialise at ~6 ns —; with several lights they spread over the lights' counters
+//     and a tile takes longer.  640-thread blocks: 10 waves do not divide over 4 SIMDs and only one block lands on a CU: +55 %.)
+#ifndef TRT_SHADE1_BLOCK
+#define TRT_SHADE1_BLOCK 512
 #endif
-#ifndef TRT_SHADE_MINWAVES
-#define TRT_SHADE_MINWAVES 0
+#ifndef TRT_SHADE1_WAVES
+#define TRT_SHADE1_WAVES 6
+#endif
+#ifndef TRT_SHADEN_BLOCK
+#define TRT_SHADEN_BLOCK 256
+#endif
+#ifndef TRT_SHADEN_WAVES
+#define TRT_SHADEN_WAVES 5
 #endif
 #ifndef TRT_SHADE_PIPE
 #define TRT_SHADE_PIPE 0
 #endif
-#if TRT_SHADE_MINWAVES > 0
-#define TRT_SHADE_BOUNDS __launch_bounds__(TRT_SHADE_BLOCK_THREADS, TRT_SHADE_MINWAVES)
-#else
-#define TRT_SHADE_BOUNDS __launch_bounds__(TRT_SHADE_BLOCK_THREADS)
-#endif
-constexpr int TRT_SHADE_BLOCK = TRT_SHADE_BLOCK_THREADS;
 constexpr int TRT_MAX_LIGHTS = 8;
 
 struct RayQueue {
@@ -843,12 +851,14 @@ struct ShadeArgs {
     uint32_t lds_mat_bytes, lds_light_bytes, lds_cum_bytes, lds_ltri_bytes, lds_tshade_bytes;
     const f4* lds_image;      // the tables of TABS, each padded to 16 B, packed in that order
     uint32_t lds_image_words;
-    uint32_t rows_lds;        // number of rows of td.rows to keep in LDS as 16-bit values (0: the tile has more than TRT_SHADE_ROWS_LDS rows, or rows >= 65536)
+    uint32_t rows_lds;        // number of rows of td.rows to keep in LDS as 16-bit values (0: the tile has more than shadeRowsLds(block) rows, or rows >= 65536)
     DeviceStats* stats;
 };
 
 constexpr uint32_t TRT_SHADE_LDS_TABLE_BYTES = 24 * 1024;
-constexpr uint32_t TRT_SHADE_ROWS_LDS = 8192;
+// rows of the tile's row table kept in LDS as 16-bit values: 8192 in 512-thread blocks (3 x 41 KB per CU), 2304 — a 4K image has 2160 — in
+// 256-thread blocks (5 x 29 KB per CU); taller tiles read the table from global memory
+constexpr uint32_t shadeRowsLds(int block) { return block >= 512 ? 8192u : 2304u; }
 
 // The tile's row table as k_shade sees it: a 16-bit copy in LDS when it fits.  The key of a path's random stream hangs on the
 // image row, i.e. on this look-up: from global memory it is a dependent load in every vertex, and — the memory counter being
@@ -886,9 +896,12 @@ struct RowsShade {
 #define TRT_STORE_BT(arr, slot, v) ((arr)[slot] = (v))
 #define TRT_LOAD_BT(arr, i, bt) ((bt) = (arr)[i])
 #endif
-template <uint32_t TABS>
-__global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
+// ONE_LIGHT: the scene has exactly one light (the loop over the lights' stages is empty at compile time).  BLOCK threads, WAVES per SIMD asked of the compiler.
+template <uint32_t TABS, bool ONE_LIGHT, int BLOCK = (ONE_LIGHT ? TRT_SHADE1_BLOCK : TRT_SHADEN_BLOCK), int WAVES = (ONE_LIGHT ? TRT_SHADE1_WAVES : TRT_SHADEN_WAVES)>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_shade(SceneDev sc, ShadeArgs A)
 {
+    constexpr int TRT_SHADE_BLOCK = BLOCK;
+    constexpr uint32_t TRT_SHADE_ROWS_LDS = shadeRowsLds(BLOCK);
     __shared__ uint32_t s_cnt[3 * (TRT_SHADE_BLOCK / 64 + 1)];
     __shared__ uint32_t s_cnt2[2 * (2 * (TRT_SHADE_BLOCK / 64) + 2)];  // blockStage2, two buffers used in turn
     __shared__ uint32_t s_shaded, s_anyhit;
@@ -986,7 +999,7 @@ __global__ TRT_SHADE_BOUNDS void k_shade(SceneDev sc, ShadeArgs A)
         uint32_t pend_rank = 0, pend_li = 0;
         f3 pend_wo = mk3(0, 0, 0), pend_w = mk3(0, 0, 0);
         float pend_tmax = TRT_INF;  // TRT_FLAG_FIXED_NEE: how far the occlusion test of the shadow ray reaches
-        const uint32_t nl = sc.n_lights;
+        const uint32_t nl = ONE_LIGHT ? 1u : sc.n_lights;
         for (uint32_t li = 0; li + 1 < nl; ++li) {  // every light but the last: a stage of its own
             bool emit = false;
             f3 wo = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
@@ -1154,6 +1167,13 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_tail(SceneDev sc, TailArgs 
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(dm, off); dm = o > dm ? o : dm; }
     if ((threadIdx.x & 63) == 0 && dm) atomicMax(&A.stats->max_depth_hit, dm - 1u);
 }
+
+// (Round 4 built a second form of this kernel — a GROUP of G >= 1 + lights lanes per path, every lane carrying the same path state, lane 0
+// tracing the extension ray into vertex k + 1 while lane 1 + l traces the shadow ray of light l from vertex k, results exchanged by wave
+// shuffles, the radiance sum in k_tail's order: bit-identical, the whole -m gpu suite green — and measured it: back 0.59 -> 0.55 ms,
+// veach-mis 0.81 -> 0.77, staircase 4.57 -> 4.55, soup 8.9 -> 10.4, the 10 M mesh 2.5 -> 3.3.  The tail is not the latency of its longest
+// path alone: with G times the lanes its early, populous bounces become throughput-bound.  Deleted (commit history has it);
+// profiles/r04_ab_shade_tail.txt has the table, with the sweep of the hand-over point TRT_TAIL_N: 131 072 is best on every scene.)
 
 // ---------------------------------------------------------------- K6 ----
 // Accumulation of main.cpp:101-108: color = L / (float)SAMPLE, image += color,
