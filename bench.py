@@ -9,7 +9,11 @@ with a single RCCL gather inside the timed region (total work fixed: strong scal
 Prints ONE JSON line on rank 0 (DESIGN.md §5 explains every field):
   value / ms_per_step     wall clock of the K timed steps (barrier + synchronize on both sides, max over ranks)
   roofline                dominant kernel of the headline: algorithmic bytes (SURVEY.md §8d canonical sizes x counts
-                          from an untimed counting render) / that kernel's hipEvent time in the timed steps
+                          from an untimed counting render) / that kernel's hipEvent time in one profiling step after the timed
+                          region; `traffic` = its HBM-side bytes per launch from two rocprofv3 --pmc child passes of the same
+                          command (FETCH_SIZE, WRITE_SIZE; run before this process touches the GPU — live_traffic()), null with
+                          the reason in `traffic_note` when the profiler cannot run; `traffic_from_profiles` = the committed
+                          counter files of profiles/ beside it
   extra_workloads         (N = 1) the other rows of BASELINE.md §3 — veach-mis, staircase at 1080p/256 spp, the 1 M-triangle
                           soup of config 3 and config 5's 10 M-triangle scene at 3840x2160 / 64 spp per pass — timed the same
                           way with fewer steps, each with its own roofline
@@ -65,6 +69,9 @@ def parse():
     ap.add_argument("--also-overlap", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--group", type=int, default=0, metavar="N", help="(N=1 process) time the C boundary of the multi-GPU path instead: trt_group_render_device over a "
                     "group of N entries, all naming device 0 on a one-GPU box (its overhead against trt_render_device is then on record)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic live "
+                    "(they run by default for the contract's own command: N = 1, the headline workload, extras on; about 30 s)")
+    ap.add_argument("--traffic", action="store_true", help="run those passes for any other N = 1 command too")
     ap.add_argument("--save-png", default=None)
     return ap.parse_args()
 
@@ -90,6 +97,64 @@ def traffic_from_profiles(scene, height, spp):
         return None
     d = json.load(open(tpath))
     return {"file": os.path.relpath(tpath, ROOT), "source": d.get("source"), "bytes_per_launch": d["bytes_per_launch"]}
+
+
+def live_traffic(a):
+    """roofline.traffic measured LIVE: before this process touches the GPU, the same command (one warm-up + one timed step, no extras) is run
+    twice as a child under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` / `--pmc WRITE_SIZE --kernel-trace` — the counters in separate passes, with
+    --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes — and the per-kernel sums are turned into HBM-side bytes per
+    launch exactly as tools/pmc_summary.py does for the committed files (reads x 2: gfx950's FETCH_SIZE counts each 128-B line as 64 B; the
+    counting kernels of the untimed counting render are left out).  Returns ({kernel: bytes per launch}, note); ({}, reason) when it cannot run —
+    never a guess.  N = 1 only."""
+    import shutil
+    import tempfile
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return {}, "not attempted: this process already runs under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {}, "not attempted: rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary as P
+    tmp = tempfile.mkdtemp(prefix="trt_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--scene", a.scene, "--width", str(a.width), "--height", str(a.height), "--spp", str(a.spp),
+             "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-overlap-extra", "--no-traffic", "--builder", a.builder]
+    if a.tris:
+        child += ["--tris", str(a.tris)]
+    if a.leaf:
+        child += ["--leaf", str(a.leaf)]
+    if a.seed is not None:
+        child += ["--seed", hex(a.seed)]
+    if a.fixed_nee:
+        child += ["--fixed-nee"]
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return {}, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or '').strip().splitlines()[-1:]}"
+            sums[counter] = P.collect(d, counter)
+        per = {}
+        for k, (n, kib) in sums["FETCH_SIZE"].items():
+            nm, counting = P.short(k)
+            if nm and not counting:
+                e = per.setdefault(nm, [0, 0.0, 0.0])
+                e[0] += n
+                e[1] += kib
+        for k, (n, kib) in sums["WRITE_SIZE"].items():
+            nm, counting = P.short(k)
+            if nm and not counting:
+                per.setdefault(nm, [0, 0.0, 0.0])[2] += kib
+        out = {nm: int((2.0 * v[1] + v[2]) * 1024 / max(v[0], 1)) for nm, v in per.items() if v[0]}
+        return out, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over this command with --steps 1 --warmup 1, "
+                     "run as child processes before the timed run; reads x 2 (gfx950 FETCH_SIZE), per launch of the non-counting kernels")
+    except Exception as e:  # a profiler that cannot run leaves traffic null, with the reason
+        return {}, f"failed: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 class Bench:
@@ -215,11 +280,21 @@ class Bench:
             achieved = dom_bytes_step * steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None,  # HBM bytes need rocprofv3 --pmc passes (tools/prof.sh); not measurable from inside this process
+                        "traffic": None,  # filled below from the live PMC passes (live_traffic) when they ran; null with the reason otherwise
                         "launches_per_step": launches[dom] // max(steps, 1),
                         "avg_launch_ms": round(dom_ms / max(launches[dom], 1), 5),
                         "algorithmic_bytes_per_launch": int(dom_bytes_step * steps / max(launches[dom], 1)),
                         "frac_of_measured_copy_peak": round(achieved / 6290.0, 4)}
+            lt = getattr(self, "live", None)
+            if lt and (scene_name, width, height, spp) == lt["key"]:
+                roofline["traffic_note"] = lt["note"]
+                if dom_name in lt["bytes"] and launches[dom] and dom_ms > 0:
+                    tb = lt["bytes"][dom_name]
+                    roofline["traffic"] = tb  # HBM-side bytes per launch of the dominant kernel, measured by the PMC passes of this very invocation
+                    roofline["traffic_GBps"] = round(tb / (dom_ms / launches[dom] * 1e-3) / 1e9, 1)
+                    roofline["traffic_frac_of_peak"] = round(roofline["traffic_GBps"] / HBM_PEAK_GBS, 4)
+                    roofline["traffic_over_algorithmic"] = round(tb / max(roofline["algorithmic_bytes_per_launch"], 1), 3)
+                    roofline["traffic_all_kernels"] = lt["bytes"]
             tp = traffic_from_profiles(scene_name, height, spp) if (world == 1 and width * 9 == height * 16) else None
             if tp and dom_name in tp["bytes_per_launch"] and launches[dom] and dom_ms > 0:
                 tb = tp["bytes_per_launch"][dom_name]
@@ -227,6 +302,21 @@ class Bench:
                 roofline["traffic_from_profiles"] = {"file": tp["file"], "bytes_per_launch": tb, "GBps_at_live_launch_time": round(meas, 1),
                                                      "frac": round(meas / HBM_PEAK_GBS, 4),
                                                      "over_algorithmic": round(tb / max(roofline["algorithmic_bytes_per_launch"], 1), 3)}
+            # the same account for every path kernel (the dominant one changes with the workload: since round 4 `back` spends 28 / 26 / 23 ms in closest hits /
+            # shade / shadow rays): algorithmic bytes per launch, live launch time, and the live counter bytes where the PMC passes ran
+            per_kernel = {}
+            for k in range(len(names)):
+                if names[k] in by and kernel_ms[k] > 0 and launches[k]:
+                    alg_pl = by[names[k]] * steps / launches[k]
+                    e = {"avg_launch_ms": round(kernel_ms[k] / launches[k], 5), "algorithmic_bytes_per_launch": int(alg_pl),
+                         "achieved_GBps": round(alg_pl / (kernel_ms[k] / launches[k] * 1e-3) / 1e9, 1)}
+                    e["frac"] = round(e["achieved_GBps"] / HBM_PEAK_GBS, 4)
+                    if lt and (scene_name, width, height, spp) == lt["key"] and names[k] in lt["bytes"]:
+                        e["traffic"] = lt["bytes"][names[k]]
+                        e["traffic_GBps"] = round(e["traffic"] / (kernel_ms[k] / launches[k] * 1e-3) / 1e9, 1)
+                        e["traffic_frac_of_peak"] = round(e["traffic_GBps"] / HBM_PEAK_GBS, 4)
+                    per_kernel[names[k]] = e
+            roofline["by_kernel"] = per_kernel
             if achieved > HBM_PEAK_GBS:
                 roofline["note"] = ("algorithmic bytes (every node / triangle record a ray touches) exceed the HBM peak because the scene is "
                                     "served from L1/L2/Infinity Cache; the kernel is bound by VALU/SALU issue and the CU's texture-address rate, not by HBM (DESIGN.md 5)")
@@ -292,6 +382,12 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a))
+    live = None
+    contract_cmd = (a.scene, a.width, a.height, a.spp) == ("back", 1920, 1080, 256) and not a.no_extra and not a.fixed_nee and not a.overlap and a.leaf is None and a.tris is None
+    if a.gpus == 1 and "WORLD_SIZE" not in os.environ and not a.no_traffic and not a.group and (contract_cmd or a.traffic):
+        t_pmc = time.time()
+        by, note = live_traffic(a)  # child processes; this process has not touched the GPU yet
+        live = {"key": (a.scene, a.width, a.height, a.spp), "bytes": by, "note": note + f" ({time.time() - t_pmc:.0f} s)"}
     import torch
     import tinyraytracing_amd as T
 
@@ -318,6 +414,7 @@ def main():
             dist.init_process_group(backend)
 
     B = Bench(a, world, rank, local_rank, dist, backend)
+    B.live = live
     seed = a.seed if a.seed is not None else SEEDS[a.scene]
     res, scene = B.measure(a.scene, a.width, a.height, a.spp, a.steps, a.warmup, seed, leaf=a.leaf, tris=a.tris,
                            base_flags=T.TRT_FLAG_OVERLAP if a.overlap else 0, also_overlap=not a.no_overlap_extra, save_png=a.save_png)

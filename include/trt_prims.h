@@ -30,6 +30,23 @@
 #define TRT_HD
 #endif
 
+/* The ONE place where the sources shared by the HIP kernels and their CPU build (tests/hostsim, the oracle) differ by compiler: loop-unroll hints and
+ * three integer bit operations whose device spelling is a HIP intrinsic.  Same results on both sides by definition of the operations (x != 0 where noted). */
+#if defined(__HIPCC__)
+#define TRT_UNROLL _Pragma("unroll")
+#else
+#define TRT_UNROLL
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+static inline __device__ uint32_t trt_clz32(uint32_t x) { return (uint32_t)__clz((int)x); }       /* x != 0 */
+static inline __device__ uint32_t trt_ctz32(uint32_t x) { return (uint32_t)__ffs((int)x) - 1u; }  /* x != 0 */
+static inline __device__ uint32_t trt_popc32(uint32_t x) { return (uint32_t)__popc(x); }
+#else
+static inline uint32_t trt_clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
+static inline uint32_t trt_ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+static inline uint32_t trt_popc32(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+#endif
+
 static inline TRT_HD uint32_t trt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 static inline TRT_HD float trt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 

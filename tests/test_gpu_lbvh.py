@@ -107,7 +107,21 @@ def test_lbvh_quality_and_speed_are_on_record(capsys):
     with capsys.disabled():
         print(f"\nblob-150k: visits / tests per ray  SAH {res['auto'][0]:.2f} / {res['auto'][1]:.2f}   LBVH with SAH top {res['lbvh'][0]:.2f} / {res['lbvh'][1]:.2f}   "
               f"plain radix tree {res['radix'][0]:.2f} / {res['radix'][1]:.2f}   build (device ms, call ms) {res['lbvh'][2]} / {res['radix'][2]}")
-    assert res["lbvh"][0] < 1.25 * res["auto"][0] and res["radix"][0] < 3.0 * res["auto"][0]
+    # round 4: clusters of 16 on scenes of 50-500 k triangles: +1.2 % node visits against the host SAH tree (round 3's 2048: +11.7 %; profiles/r04_lbvh_quality.txt);
+    # the bar is VERDICT r03's "blob-150k <= +5 %" with the slack of this test's smaller image
+    assert res["lbvh"][0] < 1.06 * res["auto"][0] and res["radix"][0] < 3.0 * res["auto"][0]
+    # staircase: Morton pairs under a full SAH (clusters of 2 below 50 k triangles): +8.0 % (round 3: +20.7 %; the verdict's bar: <= +10 %)
+    st_res = {}
+    for b in ("auto", "lbvh"):
+        s = T.Scene.named("staircase", 320, 180, leaf_num=2, builder=b)
+        r = T.Renderer(s, 0)
+        _, st = r.render(T.make_params(320, 180, 4, 11, flags=T.TRT_FLAG_COUNT))
+        st_res[b] = (st.inner_visits[0] + st.inner_visits[1]) / (st.rays_camera + st.rays_shadow + st.rays_indirect)
+        r.close()
+        s.close()
+    with capsys.disabled():
+        print(f"staircase: visits per ray  SAH {st_res['auto']:.2f}   LBVH with SAH top {st_res['lbvh']:.2f} ({(st_res['lbvh'] / st_res['auto'] - 1) * 100:+.1f} %)")
+    assert st_res["lbvh"] < 1.12 * st_res["auto"]
 
 
 def test_config5_ten_million_triangles_built_on_the_device_tiles_vs_oracle():

@@ -730,9 +730,15 @@ int trt_build_lbvh(const float* tri_v, uint32_t n_tris, int leaf_num, int device
         }
     }
     // ---- the top of the tree by SAH over clusters of the radix tree (TRT_LBVH_CLUSTER triangles at most; 0: the radix tree as it is)
-    // largest cluster: 2048 triangles for the big scenes (measured: 512 and 8192 are behind on 1-10 M triangles), n / 64 for smaller ones so that
-    // the SAH top has a few dozen leaves to work with (staircase, 31 k triangles: 512 is 2 % ahead of 2048), never below 256
-    uint32_t cluster = std::min(2048u, std::max(256u, n / 64u));
+    // Largest cluster, by node visits per ray against the host SAH tree (round 4's sweeps: tools/lbvh_cluster_sweep.py, profiles/r04_lbvh_quality.txt; the CPU
+    // emulation of tools/lbvh_study.py agrees to the point):
+    //   below 50 k triangles    2      Morton PAIRS under a full SAH: staircase +8.0 % (round 3's n / 64 = 490: +20.7 %), veach-mis +12.6 % (+22.2 %), soup-50k
+    //                                  +1.3 % (+12.0 %).  On these scenes the loss sits between groups of 8 and groups of 16 Morton neighbours (staircase: 8 -> +10.4 %,
+    //                                  12 -> +9.9 %, 16 -> +22.6 %, and SAH splits INSIDE the groups of 16 do not bring it back); the host's SAH over n / 2 clusters is ~10 ms
+    //   below 500 k             16     blob-60k +2.6 % (+14.4 %), blob-150k +1.2 % (+11.7 % with round 3's 2048)
+    //   below 4 M               128    blob-2M +2.9 % (+7.4 %); soup-1M +5.2 %, the same as with 2048
+    //   above                   2048   blob-10M +5.1 %; smaller clusters are erratic there (512: +7.1 %, 64: +3.3 %) and the host's SAH over 150 k clusters takes 160 ms
+    uint32_t cluster = n < 50000u ? 2u : (n < 500000u ? 16u : (n < 4000000u ? 128u : 2048u));
     if (const char* e = std::getenv("TRT_LBVH_CLUSTER")) cluster = (uint32_t)std::max(0L, std::atol(e));
     if (cluster && cluster < (uint32_t)leaf_num) cluster = (uint32_t)leaf_num;
     uint32_t n_out = 0, depth = 0;

@@ -112,9 +112,7 @@ TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, cons
     const uint32_t nrz[2] = {nz ? hiz0 : loz0, nz ? hiz1 : loz1}, frz[2] = {nz ? loz0 : hiz0, nz ? loz1 : hiz1};
     const uint32_t meta[2] = {f2u(q1.z), f2u(q1.w)};
     uint32_t hits = 0u;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    TRT_UNROLL
     for (int h = 0; h < 2; ++h) {
         // four children at once on the packed meta bytes: inner children (0b001xxxxx) get their position xor-ed with the octant
         const uint32_t m4 = meta[h];
@@ -124,9 +122,7 @@ TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, cons
         const uint32_t bits4 = (m4 >> 5) & 0x07070707u;                         // what to set there: 1 (inner), unary count (leaf), 0 (empty)
         // (two children per v_pk_fma_f32 — 5.1 clocks per wave against 2 x 4.2, tools/valu_probe.hip — measured slower: the pairs have to
         // be assembled first; profiles/r03_ab_oct.txt.  Removed.)
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+        TRT_UNROLL
         for (int k = 0; k < 4; ++k) {
             const float tnx = fmaf(octByte(nrx[h], k), idx, onx), tny = fmaf(octByte(nry[h], k), idy, ony), tnz = fmaf(octByte(nrz[h], k), idz, onz);
             const float tfx = fmaf(octByte(frx[h], k), idx, ofx), tfy = fmaf(octByte(fry[h], k), idy, ofy), tfz = fmaf(octByte(frz[h], k), idz, ofz);
@@ -146,19 +142,11 @@ TRT_HD inline void octVisit(const OctNode* __restrict__ nodes, uint32_t ni, cons
 // The inner child to enter next: highest set bit of the hit byte (nearest octant first); clears it in `ng`.
 TRT_HD inline uint32_t octNextChild(OctGroup& ng, const OctRay& R)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t bit = 31u - (uint32_t)__clz((int)ng.y);
-#else
-    const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng.y);
-#endif
+    const uint32_t bit = 31u - trt_clz32(ng.y);
     ng.y &= ~(1u << bit);
     const uint32_t slot = (bit - 24u) ^ (R.octinv4 & 7u);
     const uint32_t imask = ng.y & 0xFFu;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t rel = (uint32_t)__popc(imask & ((1u << slot) - 1u));
-#else
-    const uint32_t rel = (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
-#endif
+    const uint32_t rel = trt_popc32(imask & ((1u << slot) - 1u));
     return ng.x + rel;
 }
 
@@ -241,11 +229,7 @@ TRT_HD inline Hit traceOctPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint3
                 octVisit(sc.onodes, ni, R, trt_cull_bound(best_t, sc.leaf_alpha), ng, tg);
             }
             while (tg.y) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                const uint32_t b = (uint32_t)__ffs((int)tg.y) - 1u;
-#else
-                const uint32_t b = (uint32_t)__builtin_ctz(tg.y);
-#endif
+                const uint32_t b = trt_ctz32(tg.y);
                 tg.y &= tg.y - 1u;
                 const TriIsect T = sc.tri_trav[tg.x + b];
                 if (COUNT) n_tri++;

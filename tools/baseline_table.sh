@@ -11,6 +11,9 @@ python bench.py --scene blob --tris 10000000 --width 3840 --height 2160 --spp 40
 python bench.py --no-extra > $out/h_back.json 2> $out/h_back.err
 python bench.py --scene veach-mis --steps 2 > $out/h_veach.json 2> $out/h_veach.err
 python bench.py --scene staircase --steps 1 > $out/h_stair.json 2> $out/h_stair.err; echo "headline done" >&2
+# the reference's own leaf size (main.cpp:76 builds with 8; every other row is on this repository's leaf-2 tree)
+python bench.py --scene veach-mis --steps 2 --leaf 8 --no-cpu-baseline > $out/h_veach_l8.json 2> $out/h_veach_l8.err
+python bench.py --scene staircase --steps 1 --leaf 8 --no-cpu-baseline > $out/h_stair_l8.json 2> $out/h_stair_l8.err; echo "leaf 8 done" >&2
 python tools/cpu_baseline.py --scene back --width 256 --height 256 --spp 4 --seconds 1 > $out/c1.json 2> $out/c1.err
 python - <<'PY'
 import json, os
@@ -22,7 +25,8 @@ def load(n):
         return None
 rows = [("2 back 1024² 256 spp", "c2"), ("3 soup-1M 1920×1080 64 spp", "c3"), ("4 staircase 1920×1080 1024 spp (on 1 GPU)", "c4"),
         ("5 blob-10M 3840×2160 4096 spp (on 1 GPU)", "c5"), ("headline back 1080p 256 spp", "h_back"), ("headline veach-mis 1080p 256 spp", "h_veach"),
-        ("headline staircase 1080p 256 spp", "h_stair")]
+        ("headline staircase 1080p 256 spp", "h_stair"), ("veach-mis 1080p 256 spp, leaf 8 (the reference's buildBVH(..., 8))", "h_veach_l8"),
+        ("staircase 1080p 256 spp, leaf 8", "h_stair_l8")]
 c1 = load("c1")
 print("| Config | GPUs | Rays traced / step | Time (ms) | Mrays/s | Algorithmic bytes / step | Achieved GB/s (all kernels) | % of 8.0 TB/s | % of 6.29 TB/s | dominant kernel: GB/s (frac) | CPU Mrays/s (cores) | GPU/CPU |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")

@@ -20,13 +20,19 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sizes = {"back": (257, 131), "veach-mis": (320, 180), "staircase": (192, 108), "soup": (160, 90)}
-    scenes, renderers, alt, scenes_gpu_tree, on_gpu_tree = {}, {}, {}, {}, {}
+    scenes, renderers, alt, scenes_gpu_tree, on_gpu_tree, scenes_leaf8, on_leaf8 = {}, {}, {}, {}, {}, {}, {}
     for name, (w, h) in sizes.items():
         scenes[name] = T.Scene.named(name, w, h, **({"n": 50000} if name == "soup" else {}))
         renderers[name] = T.Renderer(scenes[name], 0)
         # a third handle per scene on the tree of the GPU builder (include/trt_build.h): the oracle walks that tree for it
         scenes_gpu_tree[name] = T.Scene.named(name, w, h, builder="lbvh", **({"n": 50000} if name == "soup" else {}))
         on_gpu_tree[name] = T.Renderer(scenes_gpu_tree[name], 0)
+        # a fourth handle per scene on a tree with the REFERENCE's leaf size (main.cpp:76 builds with 8): leaves of 4..8 triangles laid out as several slots of the
+        # 8-wide nodes (round 4); the tiny scene per lane, so that it walks those nodes too
+        scenes_leaf8[name] = T.Scene.named(name, w, h, leaf_num=8, **({"n": 50000} if name == "soup" else {}))
+        os.environ["TRT_TRACE_IMPL"] = "3"
+        on_leaf8[name] = T.Renderer(scenes_leaf8[name], 0)
+        del os.environ["TRT_TRACE_IMPL"]
         # a second handle per scene on the OTHER node kind of the traversal kernels (exact 4-wide nodes where the default is the 8-wide
         # compressed ones), and per-lane traversal instead of the uniform walk for the tiny scene
         os.environ["TRT_NODE_KIND"] = "0"
@@ -62,14 +68,14 @@ def main():
         if not T.rows_selected(p):
             continue
         pick = rng.random()
-        use = on_gpu_tree if pick < 0.25 else (alt if pick < 0.55 else renderers)
+        use = on_gpu_tree if pick < 0.2 else (alt if pick < 0.45 else (on_leaf8 if pick < 0.7 else renderers))
         try:
             img, st = use[name].render(p)
         except T.TrtError as e:
             if "mem_budget too small" in str(e):
                 continue
             raise
-        ref, ost = O.render((scenes_gpu_tree if use is on_gpu_tree else scenes)[name].flat, p)
+        ref, ost = O.render((scenes_gpu_tree if use is on_gpu_tree else (scenes_leaf8 if use is on_leaf8 else scenes))[name].flat, p)
         ok = np.array_equal(img, ref) and (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
         n += 1
         if not ok:

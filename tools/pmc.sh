@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 g=0
 for grp in "$@"; do
   g=$((g+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/g$g -- python3 $root/bench.py $args --steps 1 --warmup 1 --no-cpu-baseline > $out/g$g.json 2> $out/g$g.err || echo "group $g failed"
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/g$g -- python3 $root/bench.py $args --steps 1 --warmup 1 --no-cpu-baseline --no-traffic > $out/g$g.json 2> $out/g$g.err || echo "group $g failed"
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections

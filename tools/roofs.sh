@@ -15,7 +15,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CY
            "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   g=$((g+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/g$g -- python3 $root/bench.py $args --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-overlap-extra > $out/g$g.json 2> $out/g$g.err || echo "group $g failed"
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/g$g -- python3 $root/bench.py $args --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-overlap-extra --no-traffic > $out/g$g.json 2> $out/g$g.err || echo "group $g failed"
 done
 python3 $root/tools/roofs_summary.py $out "$tag: bench.py $args --steps 1 --warmup 1" > $out/summary.txt
 cat $out/summary.txt
