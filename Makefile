@@ -24,7 +24,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fa
             -mllvm -amdgpu-atomic-optimizer-strategy=None \
             -Wall -Wextra -Wno-unused-parameter -Iinclude -I$(PKG)/csrc
 
-HOST_SRC := $(PKG)/host/scene.cpp $(PKG)/host/bvh.cpp $(PKG)/host/synth.cpp $(PKG)/host/image_out.cpp $(PKG)/host/jpeg.cpp $(PKG)/host/capi.cpp
+HOST_SRC := $(PKG)/host/scene.cpp $(PKG)/host/bvh.cpp $(PKG)/host/synth.cpp $(PKG)/host/image_out.cpp $(PKG)/host/jpeg.cpp $(PKG)/host/png.cpp $(PKG)/host/capi.cpp
 HOST_HDR := $(wildcard $(PKG)/host/*.h) include/trt.h include/trt_host.h include/trt_prims.h
 HIP_SRC := $(PKG)/csrc/trt_api.hip
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) include/trt.h include/trt_prims.h include/trt_exact.h

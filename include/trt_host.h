@@ -71,9 +71,12 @@ int trth_tonemap(const float* linear_rgb, int width, int height, uint8_t* out);
 int trth_write_png(const char* path, int width, int height, const float* linear_rgb);
 int trth_write_png_bytes(const char* path, int width, int height, const uint8_t* rgb);
 
-/* Material::readinMap()'s JPEG path (material.cpp:3-11 uses cv::imread): baseline JPEG -> 8-bit RGB with libjpeg's
+/* Material::readinMap()'s JPEG path (material.cpp:3-11 uses cv::imread): baseline or progressive JPEG -> 8-bit RGB with libjpeg's
  * arithmetic.  Call with rgb = NULL to get the size first. */
 int trth_decode_jpeg(const char* path, int* width, int* height, uint8_t* rgb, uint64_t rgb_capacity);
+/* ... and its PNG path: any colour type and bit depth, interlaced or not -> 8-bit RGB as cv::imread's default flag yields it (palette expanded, grey
+ * replicated, 16-bit samples stripped to the high byte, alpha dropped).  Same calling convention. */
+int trth_decode_png(const char* path, int* width, int* height, uint8_t* rgb, uint64_t rgb_capacity);
 
 /* sizeof() of the trt.h structs as the C compiler sees them, for binding self-checks:
  * bvh_node, material, light, light_tri, texture, camera, scene, params, stats, ABI version. */

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 from PIL import Image
 
+import oracle_lib as O
 import scene_util as SU
 import tinyraytracing_amd as T
 from conftest import get_scene
@@ -96,16 +97,195 @@ def test_jpeg_decoder_on_generated_images(tmp_path, size, subsampling):
     assert np.array_equal(_decode(gray), np.asarray(Image.open(gray).convert("RGB")))
 
 
+@pytest.mark.parametrize("size", [(64, 48), (37, 53), (1, 1), (17, 8), (250, 3), (300, 200)])
+def test_progressive_jpeg_decoder_is_bit_identical_to_libjpeg(tmp_path, size):
+    """SOF2 files (round 4; cv::imread reads them like any JPEG): DC / AC first and refinement scans with end-of-band runs into coefficient arrays, then the
+    baseline pipeline — against PIL (libjpeg-turbo) at three qualities and samplings, with restart markers and with optimised Huffman tables, and in grey."""
+    from PIL import ImageFile
+    old_block = ImageFile.MAXBLOCK
+    ImageFile.MAXBLOCK = 1 << 22  # (PIL's progressive writer needs the whole file in one buffer)
+    try:
+        rng = np.random.default_rng(size[0] * 7 + size[1])
+        w, h = size
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([(xx * 5 + yy * 3) % 256, (xx * yy) % 256, rng.integers(0, 256, (h, w))], -1).astype(np.uint8)
+        path = str(tmp_path / "p.jpg")
+        for subsampling in (0, 1, 2):
+            for quality in (30, 85, 97):
+                for kw in ({}, {"restart_marker_blocks": 3}, {"optimize": True}):
+                    Image.fromarray(img).save(path, quality=quality, subsampling=subsampling, progressive=True, **kw)
+                    assert open(path, "rb").read().find(b"\xff\xc2") > 0  # really SOF2
+                    assert np.array_equal(_decode(path), np.asarray(Image.open(path).convert("RGB"))), (subsampling, quality, kw)
+        Image.fromarray(img[:, :, 2]).save(path, quality=70, progressive=True)
+        assert np.array_equal(_decode(path), np.asarray(Image.open(path).convert("RGB")))
+    finally:
+        ImageFile.MAXBLOCK = old_block
+
+
 def test_jpeg_decoder_rejects_what_it_does_not_handle(tmp_path):
     lib = T._abi.load_host()
     w, h = C.c_int(), C.c_int()
-    prog = str(tmp_path / "p.jpg")
-    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(prog, progressive=True)
-    assert lib.trth_decode_jpeg(os.fsencode(prog), C.byref(w), C.byref(h), None, 0) != 0      # progressive: sidecar route
+    cmyk = str(tmp_path / "c.jpg")
+    Image.fromarray(np.zeros((16, 16, 4), np.uint8), "CMYK").save(cmyk)
+    assert lib.trth_decode_jpeg(os.fsencode(cmyk), C.byref(w), C.byref(h), None, 0) != 0      # four components: the .ppm sidecar route
     bad = str(tmp_path / "x.jpg")
     open(bad, "wb").write(b"\xff\xd8\xff\xe0garbage")
     assert lib.trth_decode_jpeg(os.fsencode(bad), C.byref(w), C.byref(h), None, 0) != 0
     assert lib.trth_decode_jpeg(os.fsencode(str(tmp_path / "missing.jpg")), C.byref(w), C.byref(h), None, 0) != 0
+
+
+def _decode_png(path):
+    lib = T._abi.load_host()
+    w, h = C.c_int(), C.c_int()
+    assert lib.trth_decode_png(os.fsencode(path), C.byref(w), C.byref(h), None, 0) == 0, lib.trth_last_error()
+    buf = np.empty((h.value, w.value, 3), np.uint8)
+    assert lib.trth_decode_png(os.fsencode(path), C.byref(w), C.byref(h), buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size) == 0
+    return buf
+
+
+def _write_png(path, width, height, depth, ctype, samples, interlace=False, palette=None, level=6, filters=None):
+    """A PNG written by hand (PIL writes neither interlaced files nor 16-bit RGB): `samples` [h, w, channels] of `depth`-bit values."""
+    import struct
+    import zlib
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    samples = np.asarray(samples).reshape(height, width, channels)
+
+    def pack(img):  # rows of one (sub-)image -> filtered scanlines
+        hh, ww = img.shape[:2]
+        out = bytearray()
+        prev = None
+        for y in range(hh):
+            row = img[y].reshape(-1)
+            if depth == 16:
+                raw = bytearray(); [raw.extend(struct.pack(">H", int(v))) for v in row]
+            elif depth == 8:
+                raw = bytearray(int(v) for v in row)
+            else:
+                bits = "".join(format(int(v), f"0{depth}b") for v in row)
+                bits += "0" * (-len(bits) % 8)
+                raw = bytearray(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+            ft = 0 if filters is None else filters[y % len(filters)]
+            bpp = max(1, channels * depth // 8)
+            line = bytearray(len(raw))
+            for x in range(len(raw)):
+                a = raw[x - bpp] if x >= bpp else 0
+                b = prev[x] if prev is not None else 0
+                c = prev[x - bpp] if (prev is not None and x >= bpp) else 0
+                if ft == 0: pred = 0
+                elif ft == 1: pred = a
+                elif ft == 2: pred = b
+                elif ft == 3: pred = (a + b) >> 1
+                else:
+                    pp = a + b - c; pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                line[x] = (raw[x] - pred) & 255
+            out.append(ft); out.extend(line)
+            prev = raw
+        return bytes(out)
+    if interlace:
+        body = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                body += pack(sub)
+    else:
+        body = pack(samples)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    z = zlib.compress(body, level)
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(int(v) for v in np.asarray(palette).reshape(-1)))
+    half = len(z) // 2
+    data += chunk(b"IDAT", z[:half]) + chunk(b"tEXt", b"k\x00v") + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")  # two IDAT chunks, an ancillary one between
+    open(path, "wb").write(data)
+
+
+def test_png_decoder_matches_pil_on_every_mode_pil_writes(tmp_path):
+    """Material::readinMap (material.cpp:3-11: cv::imread, default flag): a PNG texture comes out as 8-bit RGB — palette expanded, grey
+    replicated, alpha dropped (host/png.cpp; own inflate).  Files written by PIL in all its PNG modes, odd sizes, every compression level."""
+    rng = np.random.default_rng(5)
+    for k, (w, h) in enumerate([(64, 48), (37, 53), (1, 1), (17, 8), (250, 3), (300, 200)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        rgb = np.stack([(xx * 5 + yy * 3) % 256, (xx * yy) % 256, rng.integers(0, 256, (h, w))], -1).astype(np.uint8)
+        alpha = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        cases = {"RGB": Image.fromarray(rgb), "RGBA": Image.fromarray(np.dstack([rgb, alpha])), "L": Image.fromarray(rgb[..., 0]),
+                 "LA": Image.fromarray(np.dstack([rgb[..., 0], alpha]), "LA"), "P": Image.fromarray(rgb).quantize(37), "1": Image.fromarray(rgb[..., 2] > 127)}
+        for mode, im in cases.items():
+            path = str(tmp_path / f"t{k}_{mode}.png")
+            im.save(path, compress_level=[0, 1, 6, 9][k % 4], optimize=(k % 2 == 1))
+            ref = np.asarray(Image.open(path).convert("RGBA" if mode in ("RGBA", "LA") else "RGB"))[..., :3]  # alpha dropped, not blended
+            assert np.array_equal(_decode_png(path), ref), (mode, w, h)
+
+
+def test_png_decoder_on_hand_written_files(tmp_path):
+    """What PIL does not write: 16-bit samples (the high byte is kept, libpng's strip_16), 1 / 2 / 4-bit grey (x * 255 / (2^d - 1)) and palettes,
+    Adam7 interlace at sizes with empty passes, every scanline filter, IDAT split in two with an ancillary chunk between."""
+    rng = np.random.default_rng(9)
+    for (w, h) in ((1, 1), (2, 3), (5, 5), (9, 17), (33, 8), (40, 31)):
+        for interlace in (False, True):
+            for depth, ctype in ((16, 2), (16, 6), (16, 0), (16, 4), (8, 2), (8, 6), (8, 4), (8, 0), (4, 0), (2, 0), (1, 0), (8, 3), (4, 3), (2, 3), (1, 3)):
+                channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+                smp = rng.integers(0, 1 << depth, (h, w, channels))
+                pal = rng.integers(0, 256, (1 << min(depth, 8), 3)) if ctype == 3 else None
+                path = str(tmp_path / "h.png")
+                _write_png(path, w, h, depth, ctype, smp, interlace=interlace, palette=pal, level=int(rng.integers(0, 10)), filters=[0, 1, 2, 3, 4, 4, 3, 2, 1])
+                s8 = (smp >> 8) if depth == 16 else smp
+                if ctype == 3:
+                    ref = pal[smp[..., 0]]
+                elif ctype in (0, 4):
+                    g = s8[..., 0] * 255 // ((1 << depth) - 1) if depth < 8 else s8[..., 0]
+                    ref = np.stack([g, g, g], -1)
+                else:
+                    ref = s8[..., :3]
+                assert np.array_equal(_decode_png(path), ref.astype(np.uint8)), (w, h, interlace, depth, ctype)
+
+
+def test_png_decoder_rejects_corrupt_input(tmp_path):
+    lib = T._abi.load_host()
+    w, h = C.c_int(), C.c_int()
+    good = str(tmp_path / "g.png")
+    Image.fromarray(np.arange(48, dtype=np.uint8).reshape(4, 4, 3)).save(good)
+    raw = open(good, "rb").read()
+    for name, data in (("truncated", raw[: len(raw) // 2]), ("signature", b"\x89PNX" + raw[4:]), ("garbage", raw[:40] + bytes(200)), ("empty", b"")):
+        p = str(tmp_path / (name + ".png"))
+        open(p, "wb").write(data)
+        assert lib.trth_decode_png(os.fsencode(p), C.byref(w), C.byref(h), None, 0) != 0, name
+    assert lib.trth_decode_png(os.fsencode(str(tmp_path / "missing.png")), C.byref(w), C.byref(h), None, 0) != 0
+    # a flipped bit in the compressed stream must not crash the decoder (whether it is noticed depends on where it lands)
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        b = bytearray(raw)
+        i = int(rng.integers(33, len(b) - 12))
+        b[i] ^= 1 << int(rng.integers(0, 8))
+        p = str(tmp_path / "flip.png")
+        open(p, "wb").write(bytes(b))
+        lib.trth_decode_png(os.fsencode(p), C.byref(w), C.byref(h), None, 0)
+
+
+def test_scene_with_a_png_texture_loads_and_renders_like_the_same_texels_as_ppm(tmp_path):
+    """map_Kd pointing at a PNG goes through Material::readinMap -> host/png.cpp; the flat scene holds PIL's texels and the oracle renders the same
+    image as with the texels handed over as a PPM."""
+    import scene_util as SU
+    rng = np.random.default_rng(3)
+    tex = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)
+    Image.fromarray(np.dstack([tex, rng.integers(0, 256, (32, 48), dtype=np.uint8)])).save(str(tmp_path / "t.png"))  # RGBA: alpha is dropped
+    with open(str(tmp_path / "t.ppm"), "wb") as f:
+        f.write(b"P6\n48 32\n255\n" + tex.tobytes())
+    lines = ["vt 0 0", "vt 1 0", "vt 1 1", "vt 0 1", "vn 0 0 1", "v -1 -1 0", "v 1 -1 0", "v 1 1 0", "v -1 1 0", "v -1 -1 2", "v 1 -1 2", "v 1 1 2", "v -1 1 2"]
+    body = "usemtl tx\nf 1/1/1 2/2/1 3/3/1\nf 1/1/1 3/3/1 4/4/1\nusemtl lamp\nf 5/1/1 7/3/1 6/2/1\nf 5/1/1 8/4/1 7/3/1\n"
+    imgs = {}
+    for ext in ("png", "ppm"):
+        mtl = SU.MTL_BASIC + f"newmtl tx\nKd 0.5 0.5 0.5\nKs 0 0 0\nNs 1\nNi 1\nmap_Kd t.{ext}\n"
+        SU.write_scene(tmp_path, "s" + ext, "\n".join(lines) + "\n" + body, mtl, lights=[("lamp", (5, 5, 5))], eye=(0, 0, 1), lookat=(0, 0, 0))
+        s = SU.load(tmp_path, "s" + ext)
+        f = s.flat.contents
+        assert f.n_textures == 1 and (f.textures[0].width, f.textures[0].height) == (48, 32)
+        assert np.array_equal(np.ctypeslib.as_array(f.textures[0].rgb, shape=(32, 48, 3)), tex)
+        imgs[ext] = O.render(s.flat, T.make_params(32, 32, 4, 7))[0]
+        s.close()
+    assert np.array_equal(imgs["png"], imgs["ppm"]) and imgs["png"].max() > 0
 
 
 def test_camera_setup_and_resolution_override():

@@ -88,7 +88,7 @@ BUILD_SYMBOLS = ["trt_build_lbvh", "trt_build_last_error"]
 HOST_SYMBOLS = ["trth_scene_load", "trth_scene_load_opts", "trth_scene_drop_tris", "trth_scene_add_soup", "trth_scene_add_blob",
                 "trth_scene_build", "trth_scene_vertices", "trth_scene_adopt_bvh", "trth_scene_flat", "trth_scene_info", "trth_scene_light_area",
                 "trth_scene_material_name", "trth_scene_free", "trth_tonemap", "trth_write_png",
-                "trth_write_png_bytes", "trth_decode_jpeg", "trth_abi_sizes", "trth_last_error"]
+                "trth_write_png_bytes", "trth_decode_jpeg", "trth_decode_png", "trth_abi_sizes", "trth_last_error"]
 
 _hip = None
 _host = None
@@ -144,6 +144,7 @@ def load_host():
     lib.trth_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.trth_abi_sizes.argtypes = [C.POINTER(C.c_int64)]
     lib.trth_decode_jpeg.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_uint64]
+    lib.trth_decode_png.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_uint64]
     lib.trth_write_png_bytes.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     _host = lib
     return lib

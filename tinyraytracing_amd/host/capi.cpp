@@ -8,7 +8,10 @@
 #include "scene.h"
 #include "trt_host.h"
 
-namespace trt { bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height); }
+namespace trt {
+bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height);
+bool decodePNG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height);
+}
 
 struct trth_scene {
     trt::Scene scene;
@@ -172,11 +175,26 @@ int trth_decode_jpeg(const char* path, int* width, int* height, uint8_t* rgb, ui
     if (!path || !width || !height) return fail("trth_decode_jpeg: null argument");
     std::vector<uint8_t> px;
     int w = 0, h = 0;
-    if (!trt::decodeJPEG(path, px, w, h)) return fail("trth_decode_jpeg: not a baseline JPEG this decoder handles");
+    if (!trt::decodeJPEG(path, px, w, h)) return fail("trth_decode_jpeg: not a JPEG this decoder handles (8-bit Huffman, grey or YCbCr)");
     *width = w;
     *height = h;
     if (rgb) {
         if (rgb_capacity < px.size()) return fail("trth_decode_jpeg: buffer too small");
+        std::memcpy(rgb, px.data(), px.size());
+    }
+    return 0;
+}
+
+int trth_decode_png(const char* path, int* width, int* height, uint8_t* rgb, uint64_t rgb_capacity)
+{
+    if (!path || !width || !height) return fail("trth_decode_png: null argument");
+    std::vector<uint8_t> px;
+    int w = 0, h = 0;
+    if (!trt::decodePNG(path, px, w, h)) return fail("trth_decode_png: not a PNG this decoder handles");
+    *width = w;
+    *height = h;
+    if (rgb) {
+        if (rgb_capacity < px.size()) return fail("trth_decode_png: buffer too small");
         std::memcpy(rgb, px.data(), px.size());
     }
     return 0;

@@ -1,9 +1,9 @@
-// jpeg.cpp — baseline JPEG decoder for map_Kd textures.
+// jpeg.cpp — JPEG decoder (baseline and progressive Huffman, 8-bit, grey or YCbCr) for map_Kd textures.
 //
 // The reference loads textures with cv::imread (material.cpp:6), i.e. libjpeg's default decode.  OpenCV and
 // libjpeg headers are not available to this build, so the decode is restated here with libjpeg's own
 // arithmetic, which makes the texels bit-identical to what the reference sees:
-//   * Huffman / dequantisation per ITU T.81 (baseline, 8-bit, SOF0; restart intervals supported),
+//   * Huffman / dequantisation per ITU T.81 (8-bit; SOF0 baseline in one interleaved scan, SOF2 progressive in any sequence of scans; restart intervals),
 //   * the "islow" integer inverse DCT (13-bit constants, 2 extra bits kept between the passes),
 //   * "fancy" (triangle-filter) chroma upsampling for 2x horizontal and/or 2x vertical subsampling,
 //   * YCbCr -> RGB with 16-bit fixed-point tables.
@@ -221,6 +221,245 @@ void upsampleFancy(const Component& c, int hs, int vs, std::vector<uint8_t>& out
         }
 }
 
+// planes of samples -> interleaved RGB: grey replicated; else fancy upsampling of the chroma planes and libjpeg's YCbCr -> RGB tables
+void finishImage(std::vector<Component>& comps, int hmax, int vmax, int width, int height, std::vector<uint8_t>& rgb)
+{
+    rgb.resize((size_t)width * height * 3);
+    if (comps.size() == 1) {
+        for (int y = 0; y < height; ++y)
+            for (int x = 0; x < width; ++x) {
+                const uint8_t g = comps[0].plane[(size_t)y * comps[0].stride + x];
+                uint8_t* o = &rgb[((size_t)y * width + x) * 3];
+                o[0] = o[1] = o[2] = g;
+            }
+        return;
+    }
+    std::vector<uint8_t> up[3];
+    int uw[3], uh[3];
+    for (int k = 0; k < 3; ++k) upsampleFancy(comps[k], hmax / comps[k].h, vmax / comps[k].v, up[k], uw[k], uh[k]);
+    // jdcolor.c ycc_rgb_convert: 16-bit fixed point tables
+    int cr_r[256], cb_b[256], cr_g[256], cb_g[256];
+    for (int i = 0; i < 256; ++i) {
+        const int x = i - 128;
+        cr_r[i] = (int)((91881 * x + 32768) >> 16);    // FIX(1.40200)
+        cb_b[i] = (int)((116130 * x + 32768) >> 16);   // FIX(1.77200)
+        cr_g[i] = -46802 * x;                           // FIX(0.71414)
+        cb_g[i] = -22554 * x + 32768;                   // FIX(0.34414)
+    }
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const int Y = up[0][(size_t)y * uw[0] + x], cb = up[1][(size_t)y * uw[1] + x], cr = up[2][(size_t)y * uw[2] + x];
+            uint8_t* o = &rgb[((size_t)y * width + x) * 3];
+            o[0] = clampSample(Y + cr_r[cr]);
+            o[1] = clampSample(Y + ((cb_g[cb] + cr_g[cr]) >> 16));
+            o[2] = clampSample(Y + cb_b[cb]);
+        }
+}
+
+// ---- progressive JPEG (SOF2; ITU T.81 annex G, decoded the way libjpeg's jdphuff.c does): the scans fill a coefficient array per component — DC first / refine,
+// AC first (with end-of-band runs) / refine —, then every block is dequantised and goes through the same IDCT, upsampling and colour conversion as a baseline
+// file, so the texels are libjpeg's here too.
+struct ProgComp {
+    int bw = 0, bh = 0;            // blocks allocated (MCU-padded)
+    std::vector<int16_t> coef;     // bw * bh * 64, natural (not zigzag) order
+};
+
+bool decodeProgressive(const std::vector<uint8_t>& data, size_t pos, uint16_t qt[4][64], Huff dc[4], Huff ac[4], std::vector<Component>& comps, int restart_interval,
+                       int width, int height, std::vector<uint8_t>& rgb)
+{
+    int hmax = 1, vmax = 1;
+    for (auto& c : comps) {
+        if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2) return false;
+        hmax = c.h > hmax ? c.h : hmax;
+        vmax = c.v > vmax ? c.v : vmax;
+    }
+    for (size_t k = 1; k < comps.size(); ++k)
+        if (comps[k].h != 1 || comps[k].v != 1) return false;
+    if (comps.size() == 1) { hmax = comps[0].h = 1; vmax = comps[0].v = 1; }
+    const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+    std::vector<ProgComp> pc(comps.size());
+    for (size_t k = 0; k < comps.size(); ++k) {
+        Component& c = comps[k];
+        c.width = (width * c.h + hmax - 1) / hmax;
+        c.height = (height * c.v + vmax - 1) / vmax;
+        c.stride = mcux * c.h * 8;
+        c.rows = mcuy * c.v * 8;
+        pc[k].bw = mcux * c.h;
+        pc[k].bh = mcuy * c.v;
+        pc[k].coef.assign((size_t)pc[k].bw * pc[k].bh * 64, 0);
+    }
+    bool any_scan = false;
+    while (pos + 4 <= data.size()) {
+        if (data[pos] != 0xFF) return false;
+        const int marker = data[pos + 1];
+        if (marker == 0xFF) { ++pos; continue; }
+        if (marker == 0xD9) break;  // EOI
+        const size_t len = ((size_t)data[pos + 2] << 8) | data[pos + 3];
+        if (len < 2 || pos + 2 + len > data.size()) return false;
+        const uint8_t* seg = &data[pos + 4];
+        const size_t seglen = len - 2;
+        if (marker == 0xDB) {
+            size_t i = 0;
+            while (i < seglen) {
+                const int pq = seg[i] >> 4, tq = seg[i] & 15;
+                ++i;
+                if (tq > 3 || i + (pq ? 128 : 64) > seglen) return false;
+                for (int k = 0; k < 64; ++k) { qt[tq][kZigzag[k]] = pq ? (uint16_t)((seg[i] << 8) | seg[i + 1]) : seg[i]; i += pq ? 2 : 1; }
+            }
+        } else if (marker == 0xC4) {
+            size_t i = 0;
+            while (i + 17 <= seglen) {
+                const int tc = seg[i] >> 4, th = seg[i] & 15;
+                if (th > 3 || tc > 1) return false;
+                Huff& h = tc ? ac[th] : dc[th];
+                int total = 0;
+                for (int l = 1; l <= 16; ++l) { h.bits[l] = seg[i + l]; total += h.bits[l]; }
+                i += 17;
+                if (total > 256 || i + (size_t)total > seglen) return false;
+                std::memcpy(h.vals, seg + i, (size_t)total);
+                i += (size_t)total;
+                h.build();
+                h.present = true;
+            }
+        } else if (marker == 0xDD) {
+            if (seglen < 2) return false;
+            restart_interval = (seg[0] << 8) | seg[1];
+        } else if (marker == 0xDA) {
+            if (seglen < 1) return false;
+            const int ns = seg[0];
+            if (ns < 1 || ns > (int)comps.size() || seglen < (size_t)(1 + 2 * ns + 3)) return false;
+            int idx[4];
+            for (int k = 0; k < ns; ++k) {
+                idx[k] = -1;
+                for (size_t c = 0; c < comps.size(); ++c) if (comps[c].id == seg[1 + 2 * k]) idx[k] = (int)c;
+                if (idx[k] < 0) return false;
+                comps[idx[k]].td = seg[2 + 2 * k] >> 4;
+                comps[idx[k]].ta = seg[2 + 2 * k] & 15;
+                if (comps[idx[k]].td > 3 || comps[idx[k]].ta > 3) return false;
+            }
+            const int Ss = seg[1 + 2 * ns], Se = seg[2 + 2 * ns], Ah = seg[3 + 2 * ns] >> 4, Al = seg[3 + 2 * ns] & 15;
+            if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1)) return false;
+            for (int k = 0; k < ns; ++k) {
+                if (Ss == 0 && Ah == 0 && !dc[comps[idx[k]].td].present) return false;
+                if (Ss > 0 && !ac[comps[idx[k]].ta].present) return false;
+            }
+            const uint8_t* scan = &data[pos + 2 + len];
+            BitReader br{scan, data.data() + data.size()};
+            for (auto& c : comps) c.pred = 0;
+            int eobrun = 0, restarts_left = restart_interval;
+            const bool interleaved = ns > 1;
+            // the scan's units: MCUs (interleaved) or the blocks that cover the component's true size (one component)
+            const Component& c0 = comps[idx[0]];
+            const int ux = interleaved ? mcux : (c0.width + 7) / 8, uy = interleaved ? mcuy : (c0.height + 7) / 8;
+            const int p1 = 1 << Al, m1 = -(1 << Al);
+            auto refineNonZero = [&](int16_t& cf) {
+                if (br.get(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+            };
+            for (int yy = 0; yy < uy; ++yy)
+                for (int xx = 0; xx < ux; ++xx) {
+                    if (restart_interval && restarts_left == 0) {
+                        const uint8_t* q = br.p;  // (the reader never runs past a marker: it stops in front of it and feeds zeros)
+                        while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+                        if (q + 1 >= br.end) return false;
+                        br.p = q + 2;
+                        br.reset();
+                        for (auto& c : comps) c.pred = 0;
+                        eobrun = 0;
+                        restarts_left = restart_interval;
+                    }
+                    for (int k = 0; k < ns; ++k) {
+                        Component& c = comps[idx[k]];
+                        ProgComp& P = pc[idx[k]];
+                        const int nbx = interleaved ? c.h : 1, nby = interleaved ? c.v : 1;
+                        for (int by = 0; by < nby; ++by)
+                            for (int bx = 0; bx < nbx; ++bx) {
+                                const int bxx = interleaved ? xx * c.h + bx : xx, byy = interleaved ? yy * c.v + by : yy;
+                                int16_t* blk = &P.coef[((size_t)byy * P.bw + bxx) * 64];
+                                if (Ss == 0) {
+                                    if (Ah == 0) {
+                                        const int t = decodeSymbol(br, dc[c.td]);
+                                        if (t < 0 || t > 15) return false;
+                                        c.pred += t ? extend(br.get(t), t) : 0;
+                                        blk[0] = (int16_t)(c.pred * (1 << Al));
+                                    } else if (br.get(1)) {
+                                        blk[0] = (int16_t)(blk[0] | p1);
+                                    }
+                                } else if (Ah == 0) {
+                                    if (eobrun > 0) { --eobrun; continue; }
+                                    for (int kk = Ss; kk <= Se;) {
+                                        const int rs = decodeSymbol(br, ac[c.ta]);
+                                        if (rs < 0) return false;
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz == 0) {
+                                            if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += br.get(r); break; }
+                                            kk += 16;
+                                        } else {
+                                            kk += r;
+                                            if (kk > 63) return false;
+                                            blk[kZigzag[kk]] = (int16_t)(extend(br.get(sz), sz) * (1 << Al));
+                                            ++kk;
+                                        }
+                                    }
+                                } else {
+                                    int kk = Ss;
+                                    if (eobrun == 0) {
+                                        for (; kk <= Se; ++kk) {
+                                            const int rs = decodeSymbol(br, ac[c.ta]);
+                                            if (rs < 0) return false;
+                                            int r = rs >> 4, sz = rs & 15;
+                                            if (sz) {
+                                                sz = br.get(1) ? p1 : m1;  // (a valid stream has size 1 here)
+                                            } else if (r != 15) {
+                                                eobrun = 1 << r;
+                                                if (r) eobrun += br.get(r);
+                                                break;
+                                            }
+                                            do {
+                                                int16_t& cf = blk[kZigzag[kk]];
+                                                if (cf != 0) refineNonZero(cf);
+                                                else if (--r < 0) break;
+                                                ++kk;
+                                            } while (kk <= Se);
+                                            if (sz && kk <= 63) blk[kZigzag[kk]] = (int16_t)sz;
+                                        }
+                                    }
+                                    if (eobrun > 0) {
+                                        for (; kk <= Se; ++kk) {
+                                            int16_t& cf = blk[kZigzag[kk]];
+                                            if (cf != 0) refineNonZero(cf);
+                                        }
+                                        --eobrun;
+                                    }
+                                }
+                            }
+                    }
+                    if (restart_interval) --restarts_left;
+                }
+            any_scan = true;
+            // on to the next marker behind the entropy-coded data (0xFF00 is a stuffed byte, 0xFFD0-D7 restart markers belong to the scan)
+            size_t q = pos + 2 + len;
+            while (q + 1 < data.size() && !(data[q] == 0xFF && data[q + 1] != 0x00 && !(data[q + 1] >= 0xD0 && data[q + 1] <= 0xD7) && data[q + 1] != 0xFF)) ++q;
+            pos = q;
+            continue;
+        }
+        pos += 2 + len;
+    }
+    if (!any_scan) return false;
+    int32_t block[64];
+    for (size_t k = 0; k < comps.size(); ++k) {
+        Component& c = comps[k];
+        c.plane.assign((size_t)c.stride * c.rows, 0);
+        for (int by = 0; by < pc[k].bh; ++by)
+            for (int bx = 0; bx < pc[k].bw; ++bx) {
+                const int16_t* blk = &pc[k].coef[((size_t)by * pc[k].bw + bx) * 64];
+                for (int i = 0; i < 64; ++i) block[i] = (int32_t)blk[i] * qt[c.tq][i];
+                idctIslow(block, c.plane.data() + (size_t)(by * 8) * c.stride + (size_t)bx * 8, c.stride);
+            }
+    }
+    finishImage(comps, hmax, vmax, width, height, rgb);
+    return true;
+}
+
 }  // namespace
 
 bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height)
@@ -242,6 +481,7 @@ bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, 
     int restart_interval = 0;
     size_t pos = 2;
     const uint8_t* scan = nullptr;
+    bool progressive = false;
     while (pos + 4 <= data.size()) {
         if (data[pos] != 0xFF) return false;
         const int marker = data[pos + 1];
@@ -261,7 +501,8 @@ bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, 
                     i += pq ? 2 : 1;
                 }
             }
-        } else if (marker == 0xC0) {
+        } else if (marker == 0xC0 || marker == 0xC2) {
+            progressive = marker == 0xC2;
             if (seglen < 6 || seg[0] != 8) return false;
             height = (seg[1] << 8) | seg[2];
             width = (seg[3] << 8) | seg[4];
@@ -275,8 +516,8 @@ bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, 
                 comps[c].tq = seg[8 + 3 * c];
                 if (comps[c].tq > 3) return false;
             }
-        } else if (marker == 0xC1 || marker == 0xC2 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
-            return false;  // extended / progressive / lossless / arithmetic: not baseline
+        } else if (marker == 0xC1 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
+            return false;  // extended sequential / lossless / arithmetic coding
         } else if (marker == 0xC4) {
             size_t i = 0;
             while (i + 17 <= seglen) {
@@ -297,6 +538,7 @@ bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, 
             restart_interval = (seg[0] << 8) | seg[1];
         } else if (marker == 0xDA) {
             if (comps.empty() || seglen < 1) return false;
+            if (progressive) return decodeProgressive(data, pos, qt, dc, ac, comps, restart_interval, width, height, rgb);  // (takes over at this first scan header)
             const int ns = seg[0];
             if (ns != (int)comps.size() || seglen < (size_t)(1 + 2 * ns + 3)) return false;  // one interleaved scan
             for (int k = 0; k < ns; ++k) {
@@ -378,36 +620,7 @@ bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, 
             if (restart_interval) --restarts_left;
         }
 
-    rgb.resize((size_t)width * height * 3);
-    if (comps.size() == 1) {
-        for (int y = 0; y < height; ++y)
-            for (int x = 0; x < width; ++x) {
-                const uint8_t g = comps[0].plane[(size_t)y * comps[0].stride + x];
-                uint8_t* o = &rgb[((size_t)y * width + x) * 3];
-                o[0] = o[1] = o[2] = g;
-            }
-        return true;
-    }
-    std::vector<uint8_t> up[3];
-    int uw[3], uh[3];
-    for (int k = 0; k < 3; ++k) upsampleFancy(comps[k], hmax / comps[k].h, vmax / comps[k].v, up[k], uw[k], uh[k]);
-    // jdcolor.c ycc_rgb_convert: 16-bit fixed point tables
-    int cr_r[256], cb_b[256], cr_g[256], cb_g[256];
-    for (int i = 0; i < 256; ++i) {
-        const int x = i - 128;
-        cr_r[i] = (int)((91881 * x + 32768) >> 16);    // FIX(1.40200)
-        cb_b[i] = (int)((116130 * x + 32768) >> 16);   // FIX(1.77200)
-        cr_g[i] = -46802 * x;                           // FIX(0.71414)
-        cb_g[i] = -22554 * x + 32768;                   // FIX(0.34414)
-    }
-    for (int y = 0; y < height; ++y)
-        for (int x = 0; x < width; ++x) {
-            const int Y = up[0][(size_t)y * uw[0] + x], cb = up[1][(size_t)y * uw[1] + x], cr = up[2][(size_t)y * uw[2] + x];
-            uint8_t* o = &rgb[((size_t)y * width + x) * 3];
-            o[0] = clampSample(Y + cr_r[cr]);
-            o[1] = clampSample(Y + ((cb_g[cb] + cr_g[cr]) >> 16));
-            o[2] = clampSample(Y + cb_b[cb]);
-        }
+    finishImage(comps, hmax, vmax, width, height, rgb);
     return true;
 }
 

@@ -102,17 +102,21 @@ static bool readPPM(const std::string& path, std::vector<uint8_t>& rgb, int& w, 
 }
 
 bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height);  // jpeg.cpp
+bool decodePNG(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height);   // png.cpp
 
 bool Material::readinMap()
 {
-    // material.cpp:3-11 decodes with cv::imread.  OpenCV/libjpeg are not available: binary PPM is read
-    // directly, baseline JPEG through host/jpeg.cpp (libjpeg's integer IDCT / fancy upsampling / colour
-    // tables restated, so the texels are the ones cv::imread yields), and as a last resort the pre-decoded
-    // sidecar "<map_Kd>.ppm" written by tools/decode_textures.py (progressive or CMYK JPEGs, PNG, ...).
+    // material.cpp:3-11 decodes with cv::imread.  OpenCV/libjpeg/libpng are not available: binary PPM is read
+    // directly, baseline and progressive JPEG through host/jpeg.cpp (libjpeg's integer IDCT / fancy upsampling / colour
+    // tables restated, so the texels are the ones cv::imread yields), PNG through host/png.cpp (every colour type
+    // and depth, interlaced or not, reduced to 8-bit RGB the way imread's default flag does), and as a last resort
+    // the pre-decoded sidecar "<map_Kd>.ppm" written by tools/decode_textures.py (CMYK or arithmetic-coded JPEGs, ...).
     img.clear();
     map_width = map_height = 0;
     if (readPPM(map_Kd, img, map_width, map_height)) return true;
     if (decodeJPEG(map_Kd, img, map_width, map_height)) return true;
+    img.clear();
+    if (decodePNG(map_Kd, img, map_width, map_height)) return true;
     img.clear();
     if (readPPM(map_Kd + ".ppm", img, map_width, map_height)) return true;
     std::printf("Cannot read file: %s\n", map_Kd.c_str());
