@@ -131,7 +131,10 @@ def test_config5_ten_million_triangles_built_on_the_device_tiles_vs_oracle():
     s = T.Scene.load(os.path.join(d, "back.xml"), os.path.join(d, "back.obj"), os.path.join(d, "back.mtl"), d, 3840, 2160)
     s._check(s._lib.trth_scene_drop_tris(s._h, 6, 12))
     s._check(s._lib.trth_scene_add_blob(s._h, T.SEED_BLOB, 10_000_000))
+    import torch
+    before = torch.cuda.current_device()
     s.build_bvh(2, "lbvh")
+    assert torch.cuda.current_device() == before  # trt_build_lbvh restores the caller's device on every exit path
     assert s.info["n_triangles"] >= 10_000_000
     print(f"\nconfig 5, tree built on the device: {s.build_ms[0]:.1f} ms of kernels and host SAH top, {s.build_ms[1]:.1f} ms for the call with its copies")
     assert s.build_ms[0] < 500.0, s.build_ms  # device part only, loosely (tens of ms); the call's wall clock depends on the host's share of cores and PCIe

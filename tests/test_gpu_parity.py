@@ -754,6 +754,17 @@ def test_the_references_own_leaf_size_takes_the_oct_nodes(name, tree, monkeypatc
         assert (rst.rays_camera, rst.rays_shadow, rst.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
         pf = T.make_params(96, 54, 4, 12, flags=T.TRT_FLAG_FIXED_NEE | T.TRT_FLAG_RAY_OFFSET)
         assert_same_image(r.render(pf)[0], O.render(s.flat, pf)[0], f"{name} {tree} fixed NEE")
+        # triangles per leaf step (sc.leaf_loop: 4 on such trees) is scheduling only: any value gives the same hits
+        for ll in ("1", "3", "24"):
+            monkeypatch.setenv("TRT_LEAF_LOOP", ll)
+            r2 = T.Renderer(s, 0)
+            try:
+                t2, tri2, uv2 = r2.trace_closest(o3, d3)
+                assert np.array_equal(tri2, tri0[-len(o3):]) and np.array_equal(t2, t0[-len(o3):]) and np.array_equal(uv2, uv0[-len(o3):]), ll
+                assert_same_image(r2.render(p)[0], ref, f"{name} {tree} leaf loop {ll}")
+            finally:
+                r2.close()
+        monkeypatch.delenv("TRT_LEAF_LOOP")
     finally:
         r.close()
         s.close()
