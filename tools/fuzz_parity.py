@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
+import scene_util as SU  # noqa: E402
 import tinyraytracing_amd as T  # noqa: E402
 
 
@@ -29,7 +30,8 @@ def main():
         on_gpu_tree[name] = T.Renderer(scenes_gpu_tree[name], 0)
         # a fourth handle per scene on a tree with the REFERENCE's leaf size (main.cpp:76 builds with 8): leaves of 4..8 triangles laid out as several slots of the
         # 8-wide nodes (round 4); the tiny scene per lane, so that it walks those nodes too
-        scenes_leaf8[name] = T.Scene.named(name, w, h, leaf_num=8, **({"n": 50000} if name == "soup" else {}))
+        # (the shipped scenes: the tree of the REFERENCE's builder as the oracle restates it, bvh.cpp:16-144; the soup: this repository's builder with leaf 8)
+        scenes_leaf8[name] = T.Scene.named(name, w, h, leaf_num=8, n=50000) if name == "soup" else SU.load_with_reference_tree(name, w, h, 8)
         os.environ["TRT_TRACE_IMPL"] = "3"
         on_leaf8[name] = T.Renderer(scenes_leaf8[name], 0)
         del os.environ["TRT_TRACE_IMPL"]
