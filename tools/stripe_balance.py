@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--ranks", default="2,4,8")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--overlap", action="store_true", help="TRT_FLAG_OVERLAP: two sample passes in flight (what render() / tinyrt ship with)")
     a = ap.parse_args()
     W, H, spp, seed = a.width, a.height, a.spp, SEEDS[a.scene]
     s = T.Scene.named(a.scene, W, H, n=a.tris)
@@ -44,7 +45,7 @@ def main():
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
 
     def timed(rows):
-        p = T.make_params(W, H, spp, seed, rows=rows)
+        p = T.make_params(W, H, spp, seed, rows=rows, flags=T.TRT_FLAG_OVERLAP if a.overlap else 0)
         r.render_into(p, out)  # warm-up (allocations, caches)
         torch.cuda.synchronize()
         best = 1e30
