@@ -305,7 +305,9 @@ inline V3 sampleDir(V3 a, int ray_type, float Ns, float u_phi, float u_theta)
 
 // ---------------------------------------------------------- nextRay (a11) ----
 // pathTracing.cpp:147-209.  `I` is the incoming direction (= -wi).
-inline int nextRay(const trt_material& m, V3 pn, V3 I, Stream& rng, V3& out)
+// `mirror_on_fresnel` (ORACLE_MODE_EXPERIMENT_GLASS_MIRROR, never the parity path): a dielectric whose Fresnel draw says "reflect" reflects specularly instead of
+// falling through to the opaque lobes as pathTracing.cpp:173-194 does.
+inline int nextRay(const trt_material& m, V3 pn, V3 I, Stream& rng, V3& out, bool mirror_on_fresnel = false)
 {
     if (m.Ni > 1.0f) {
         const float cos_in = dot(I, pn);
@@ -324,6 +326,7 @@ inline int nextRay(const trt_material& m, V3 pn, V3 I, Stream& rng, V3& out)
             out = reflect(I, n);  // total internal reflection
             return TRT_RAY_SPECULAR;
         }
+        if (mirror_on_fresnel) { out = reflect(I, n); return TRT_RAY_SPECULAR; }
     }
     const float Kd_len = length(ld(m.Kd)), Ks_len = length(ld(m.Ks));
     const float kd = Kd_len / (Kd_len + Ks_len), ks = Ks_len / (Kd_len + Ks_len);
@@ -360,6 +363,7 @@ struct PathTracer {
     // pathTracing.cpp:84, tried against the reference's `back` snapshots.  Never set by tests of the parity path.
     bool experiment_no_rr_div = false;
     bool experiment_specular_ks = false;  // ORACLE_MODE_EXPERIMENT_SPECULAR_KS (oracle.h): a SPECULAR bounce weighted by the material's Ks instead of the texel Kd
+    bool experiment_glass_mirror = false, experiment_no_tr_on_emitter = false, experiment_no_nee_on_glass = false;  // the three glass hypotheses of VERDICT r03 (oracle.h)
 
     PathTracer(const SceneView& v, Counters& c) : sv(v), cnt(c) {}
 
@@ -463,7 +467,7 @@ struct PathTracer {
     // ITERATIVE form of shade(): L += beta * L_dir per vertex; beta = (beta*w)/P_RR per bounce.
     V3 pathIterative(V3 o, V3 d, Stream& rng, int max_depth, float* dbg = nullptr, int dbg_cap = 0, int* dbg_n = nullptr)
     {
-        V3 L = mk(0, 0, 0), beta = mk(1, 1, 1);
+        V3 L = mk(0, 0, 0), beta = mk(1, 1, 1), beta_before_last = mk(1, 1, 1);  // (the latter: beta without the last bounce's Tr, for one experiment)
         int prev_type = -1;  // camera
         cnt.rays[0]++;
         for (uint32_t depth = 0;; ++depth) {
@@ -476,22 +480,23 @@ struct PathTracer {
                     // pathTracing.cpp:9-12 returns the radiance; the caller keeps it only for the
                     // camera ray (main.cpp:101) and for TRANSMISSION (pathTracing.cpp:87-96, Q9)
                     if (depth == 0) L = L + ld(hm.radiance);
-                    else if (prev_type == TRT_RAY_TRANSMISSION) L = L + beta * ld(hm.radiance);
+                    else if (prev_type == TRT_RAY_TRANSMISSION) L = L + (experiment_no_tr_on_emitter ? beta_before_last : beta) * ld(hm.radiance);
                 } else {
                     cnt.shaded++;
                     const Vertex vx = makeVertex(h, o, d);
                     for (uint32_t li = 0; li < sv.s->n_lights; ++li) {
                         V3 c;
-                        if (lightSample(vx, li, rng, c)) L = L + beta * c;
+                        if (lightSample(vx, li, rng, c) && !(experiment_no_nee_on_glass && vx.m->Ni > 1.0f)) L = L + beta * c;  // (the draws are consumed either way)
                     }
                     const bool last = max_depth > 0 && (int)depth + 1 >= max_depth;
                     if (!last && rng.next() < TRT_P_RR) {  // RR, pathTracing.cpp:78,104-109
                         V3 nd;
-                        const int type = nextRay(*vx.m, vx.pn, d, rng, nd);
+                        const int type = nextRay(*vx.m, vx.pn, d, rng, nd, experiment_glass_mirror);
                         type_out = type;
                         if (type != TRT_RAY_INVALID) {
                             V3 w = (type == TRT_RAY_TRANSMISSION) ? ld(vx.m->Tr) : vx.Kd;  // Q8
                             if (experiment_specular_ks && type == TRT_RAY_SPECULAR) w = ld(vx.m->Ks);
+                            beta_before_last = experiment_no_rr_div ? beta : beta / TRT_P_RR;
                             beta = experiment_no_rr_div ? beta * w : (beta * w) / TRT_P_RR;
                             o = rayOrigin(vx, nd);  // Q6: no offset unless TRT_FLAG_RAY_OFFSET
                             d = nd;
@@ -599,8 +604,13 @@ int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, o
 {
     const bool no_rr_div = (mode & ORACLE_MODE_EXPERIMENT_NO_RR_DIV) != 0;
     const bool specular_ks = (mode & ORACLE_MODE_EXPERIMENT_SPECULAR_KS) != 0;
-    mode &= ~(ORACLE_MODE_EXPERIMENT_NO_RR_DIV | ORACLE_MODE_EXPERIMENT_SPECULAR_KS);
-    if (specular_ks && mode != ORACLE_MODE_ITERATIVE) return TRT_EINVAL;
+    const bool glass_mirror = (mode & ORACLE_MODE_EXPERIMENT_GLASS_MIRROR) != 0, no_tr_emit = (mode & ORACLE_MODE_EXPERIMENT_NO_TR_ON_EMITTER) != 0,
+               no_nee_glass = (mode & ORACLE_MODE_EXPERIMENT_NO_NEE_ON_GLASS) != 0;
+    const int exp_bits = ORACLE_MODE_EXPERIMENT_NO_RR_DIV | ORACLE_MODE_EXPERIMENT_SPECULAR_KS | ORACLE_MODE_EXPERIMENT_GLASS_MIRROR | ORACLE_MODE_EXPERIMENT_NO_TR_ON_EMITTER |
+                         ORACLE_MODE_EXPERIMENT_NO_NEE_ON_GLASS;
+    const bool any_new_exp = specular_ks || glass_mirror || no_tr_emit || no_nee_glass;
+    mode &= ~exp_bits;
+    if (any_new_exp && mode != ORACLE_MODE_ITERATIVE) return TRT_EINVAL;
     if (int e = checkParams(scene, p)) return e;
     if (!out_rgb) return TRT_EINVAL;
     const SceneView sv(scene);
@@ -619,6 +629,9 @@ int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, o
         pt.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) != 0;
         pt.experiment_no_rr_div = no_rr_div;
         pt.experiment_specular_ks = specular_ks;
+        pt.experiment_glass_mirror = glass_mirror;
+        pt.experiment_no_tr_on_emitter = no_tr_emit;
+        pt.experiment_no_nee_on_glass = no_nee_glass;
 #pragma omp for schedule(dynamic, 1)
         for (long r = 0; r < (long)rows.size(); ++r) {
             const int i = rows[(size_t)r];

@@ -33,6 +33,12 @@ typedef struct oracle_stats {
                                                   * pathTracing.cpp:91-93 multiplies by (Q8) — an experiment against the reference's staircase snapshots, whose teal
                                                   * Metal strip (Kd 0.2, Ks 0 0.8 0.8) the committed weighting cannot produce; never the parity path. */
 
+/* The three glass hypotheses VERDICT r03 listed for the staircase residual, each an explicit bit (iterative form; tests/test_ref_png.py measures what each explains —
+ * nothing: the residual is the weight of SPECULAR bounces, above): */
+#define ORACLE_MODE_EXPERIMENT_GLASS_MIRROR 0x400       /* Ni > 1 and the Fresnel draw says "reflect": a mirror reflection instead of the fall-through to the opaque lobes (pathTracing.cpp:173-194) */
+#define ORACLE_MODE_EXPERIMENT_NO_TR_ON_EMITTER 0x800   /* an emitter reached through a TRANSMISSION bounce is not weighted by that bounce's Tr (pathTracing.cpp:95-96 weights it) */
+#define ORACLE_MODE_EXPERIMENT_NO_NEE_ON_GLASS 0x1000   /* no next-event estimation at vertices on Ni > 1 surfaces (pathTracing.cpp:34-74 samples the lights there too) */
+
 /* main.cpp:80-113 restated.  Same trt_params semantics as trt_render (tile,
  * row interleave, packed float output).  threads <= 0 -> all cores. */
 int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats,

@@ -14,6 +14,7 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 MODE_ITERATIVE, MODE_RECURSIVE = 0, 1
 MODE_EXPERIMENT_NO_RR_DIV = 0x100  # or-ed into `mode`: oracle.h
 MODE_EXPERIMENT_SPECULAR_KS = 0x200
+MODE_EXPERIMENT_GLASS_MIRROR, MODE_EXPERIMENT_NO_TR_ON_EMITTER, MODE_EXPERIMENT_NO_NEE_ON_GLASS = 0x400, 0x800, 0x1000
 TRACE_REFERENCE, TRACE_BRUTE = 0, 1
 
 

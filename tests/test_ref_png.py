@@ -252,6 +252,36 @@ def test_staircase_snapshots_weight_specular_bounces_by_ks():
     assert teal_c[0] > teal_c[1] > teal_c[2]                                                   # the committed weighting: dim and warm
 
 
+def test_the_glass_hypotheses_explain_none_of_the_staircase_residual():
+    """VERDICT r03 task 1 (c): the three glass-path hypotheses for staircase's residual, each an explicit mode bit of the test oracle — (i) a mirror reflection instead of the
+    fall-through to the opaque lobes when the Fresnel draw says "reflect" (pathTracing.cpp:173-194), (ii) no Tr on an emitter reached through a TRANSMISSION bounce (:95-96),
+    (iii) no next-event estimation on Ni > 1 surfaces (:34-74) — judged like the Ks weight in the test above: an explanation brings the mean to 1, the three channels together
+    AND the block error to its floor.  Measured on the lower 420 rows at 10 spp (mean / spread of the channel ratios / median block error; the test itself runs the
+    three hypotheses on the lowest 260 rows — 1.133 / 1.101 / 10.2 %, 1.136 / 1.105 / 10.4 %, 0.990 / 1.160 / 7.2 % there — to keep the CPU suite short):
+        committed            1.0934 / 1.076 / 7.1 %
+        SPECULAR by Ks       0.9995 / 1.001 / 2.5 %   <- the explanation (two-seed floor 2.2 %)
+        (i)  glass mirror    1.0944 / 1.078 / 7.2 %   nothing
+        (ii) no Tr on emit.  1.0978 / 1.081 / 7.5 %   nothing, wrong way
+        (iii) no NEE glass   0.9625 / 1.124 / 6.2 %   moves the MEAN past 1 (the balustrade's diffuse reflection is a tenth of these rows' light) but tears the channels
+                                                      further apart and leaves the blocks as wrong as before: a different picture, not the snapshot's
+    Only 17.7 % of the image's energy crosses a glass interface at all (profiles/r04_staircase_residual.txt)."""
+    png = _png("staircase_image10.png")
+    h, w = png.shape[:2]
+    y0 = 460
+    s = get_scene("staircase", w, h)
+    p = T.make_params(w, h, 10, SEEDS["staircase"], tile=(0, y0, w, h))
+    rb = _blocks(_lin8(png[y0:]))
+
+    def stats(mode):
+        ob = _blocks(_lin8(T.tonemap(O.render(s.flat, p, mode=O.MODE_ITERATIVE | mode)[0])))
+        ch = ob.mean((0, 1)) / rb.mean((0, 1))
+        return float(ob.mean() / rb.mean()), float(ch.max() / ch.min()), float(np.median(np.abs(ob - rb) / (0.02 + rb)))
+    for name, bit in (("glass_mirror", O.MODE_EXPERIMENT_GLASS_MIRROR), ("no_tr_on_emitter", O.MODE_EXPERIMENT_NO_TR_ON_EMITTER), ("no_nee_on_glass", O.MODE_EXPERIMENT_NO_NEE_ON_GLASS)):
+        mean, spread, med = stats(bit)
+        print(f"{name}: mean {mean:.4f}, channel spread {spread:.4f}, median block error {med:.4f}")
+        assert spread >= 1.05 and med >= 0.05, (name, mean, spread, med)   # the colour signature and the block error stay: not an explanation
+
+
 # ------------------------------------------------------------------------------------------------ HIP path
 # fixture -> (samples per pixel of the snapshot = what the HIP render uses, max median block error, max p90, min correlation)
 GPU_BOUNDS = {
