@@ -155,6 +155,11 @@ typedef struct trt_scene {
                                   * hit triangle's geometric normal, s the side the ray leaves to, eps = 1e-4 * max(1, |P.x|, |P.y|, |P.z|).
                                   * Off = parity mode. */
 #define TRT_OFFSET_EPS 0.0001f
+#define TRT_FLAG_SPECULAR_KS 64u /* the look of the reference's own saved renders: the light that returns along a SPECULAR bounce is weighted by the material's Ks —
+                                  * what the revision that wrote example-scenes-cg22/staircase/image*.png did — instead of the texel Kd the committed source
+                                  * multiplies by (pathTracing.cpp:91-93, quirk Q8).  With it the HIP path reproduces staircase/image256.png to its noise floor
+                                  * (profiles/r04_staircase_residual.txt); scenes whose glossy materials have Kd = Ks (veach-mis) or none (back) do not change.
+                                  * Off = parity with the committed source. */
 
 typedef struct trt_params {
     int32_t width, height;   /* full image size (scene.img_width/height, scene.cpp:13-14) */

@@ -545,7 +545,7 @@ struct PathTracer {
                     const V3 intensity = shadeRecursive(ret, no, nd, rng, depth + 1) / TRT_P_RR;
                     const bool ret_emissive = sv.emissive(ret.tri);
                     if (type == TRT_RAY_TRANSMISSION) L_indir = L_indir + ld(vx.m->Tr) * intensity;
-                    else if (!ret_emissive) L_indir = L_indir + vx.Kd * intensity;
+                    else if (!ret_emissive) L_indir = L_indir + ((experiment_specular_ks && type == TRT_RAY_SPECULAR) ? ld(vx.m->Ks) : vx.Kd) * intensity;
                 }
             }
         }
@@ -603,12 +603,12 @@ extern "C" {
 int oracle_render(const trt_scene* scene, const trt_params* p, float* out_rgb, oracle_stats* stats, int threads, int mode)
 {
     const bool no_rr_div = (mode & ORACLE_MODE_EXPERIMENT_NO_RR_DIV) != 0;
-    const bool specular_ks = (mode & ORACLE_MODE_EXPERIMENT_SPECULAR_KS) != 0;
+    const bool specular_ks = (mode & ORACLE_MODE_EXPERIMENT_SPECULAR_KS) != 0 || (p && (p->flags & TRT_FLAG_SPECULAR_KS) != 0);  // the mode bit predates the flag
     const bool glass_mirror = (mode & ORACLE_MODE_EXPERIMENT_GLASS_MIRROR) != 0, no_tr_emit = (mode & ORACLE_MODE_EXPERIMENT_NO_TR_ON_EMITTER) != 0,
                no_nee_glass = (mode & ORACLE_MODE_EXPERIMENT_NO_NEE_ON_GLASS) != 0;
     const int exp_bits = ORACLE_MODE_EXPERIMENT_NO_RR_DIV | ORACLE_MODE_EXPERIMENT_SPECULAR_KS | ORACLE_MODE_EXPERIMENT_GLASS_MIRROR | ORACLE_MODE_EXPERIMENT_NO_TR_ON_EMITTER |
                          ORACLE_MODE_EXPERIMENT_NO_NEE_ON_GLASS;
-    const bool any_new_exp = specular_ks || glass_mirror || no_tr_emit || no_nee_glass;
+    const bool any_new_exp = (mode & ORACLE_MODE_EXPERIMENT_SPECULAR_KS) != 0 || glass_mirror || no_tr_emit || no_nee_glass;
     mode &= ~exp_bits;
     if (any_new_exp && mode != ORACLE_MODE_ITERATIVE) return TRT_EINVAL;
     if (int e = checkParams(scene, p)) return e;
@@ -903,6 +903,7 @@ int oracle_debug_path(const trt_scene* scene, const trt_params* p, int x, int y,
     PathTracer pt(sv, cnt);
     pt.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) != 0;
     pt.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) != 0;
+    pt.experiment_specular_ks = (p->flags & TRT_FLAG_SPECULAR_KS) != 0;
     const uint32_t pixel = (uint32_t)y * (uint32_t)p->width + (uint32_t)x;
     Stream rng{trt_rng_make_key(p->seed, pixel, (uint32_t)sample), 0};
     const float u1 = rng.next(), u2 = rng.next();

@@ -175,6 +175,7 @@ struct Literal {
     std::vector<double> light_area;               // Material::area per light (scene.cpp:202)
     std::vector<std::vector<double>> light_cum;   // Triangle::area of the light's copies (scene.cpp:203)
     bool ray_offset = false;  // TRT_FLAG_RAY_OFFSET (not the reference's: lets the tolerance be measured with Q6 out of the way)
+    bool specular_ks = false; // TRT_FLAG_SPECULAR_KS: `case SPECULAR: L_indir += m.Ks * intensity` — what the revision behind the staircase snapshots had — instead of the committed Kd (pathTracing.cpp:91-93)
     // origin of a ray leaving the hit in direction w: the hit point, or eps off the surface on w's side (include/trt.h)
     V3 rayOrigin(const HitRecord& rec, V3 w) const
     {
@@ -398,7 +399,7 @@ struct Literal {
                 if (ret.is_hit) {
                     const V3 intensity = shade(ret, -nd, rng, cnt, depth + 1) / TRT_P_RR;
                     if (type == TRT_RAY_TRANSMISSION) L_indir = L_indir + ld(m.Tr) * intensity;
-                    else if (!emissive(ret.tri)) L_indir = L_indir + Kd * intensity;
+                    else if (!emissive(ret.tri)) L_indir = L_indir + ((specular_ks && type == TRT_RAY_SPECULAR) ? ld(m.Ks) : Kd) * intensity;
                 }
             }
         }
@@ -425,6 +426,7 @@ int oracle_render_literal(const trt_scene* scene, const trt_params* p, float* ou
     if (p->max_depth != 0 || (p->flags & (TRT_FLAG_FIXED_NEE | TRT_FLAG_FIXED_PIXELS))) return TRT_EINVAL;  // the reference has neither
     Literal lit(scene);
     lit.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) != 0;
+    lit.specular_ks = (p->flags & TRT_FLAG_SPECULAR_KS) != 0;
     std::vector<int> rows;
     for (int y = p->y0; y < p->y1; ++y)
         if (rowSelected(p, y)) rows.push_back(y);

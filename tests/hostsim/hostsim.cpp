@@ -169,6 +169,7 @@ extern "C" int hostsim_render(const trt_scene* s, const trt_params* p, float* ou
     td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
     td.fixed_pixels = (p->flags & TRT_FLAG_FIXED_PIXELS) ? 1u : 0u;
     td.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) ? 1u : 0u;
+    td.specular_ks = (p->flags & TRT_FLAG_SPECULAR_KS) ? 1u : 0u;
     td.npix_magic = magicOf(npix); td.tile_w_magic = magicOf(tw);
     td.grid_ok = 0u;  // the host form of cameraRay divides
     for (double& g : td.grid_rcp) g = 0.0;

@@ -770,6 +770,19 @@ def test_the_references_own_leaf_size_takes_the_oct_nodes(name, tree, monkeypatc
         s.close()
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("staircase", 96, 54, 8), ("veach-mis", 96, 54, 8), ("back", 64, 64, 8)])
+def test_specular_ks_flag_matches_oracle(name, w, h, spp, renderer_factory):
+    """TRT_FLAG_SPECULAR_KS, alone and with the other estimator flags: bit-identical to the oracle that takes the same switch."""
+    s = get_scene(name, w, h)
+    r = renderer_factory(s)
+    for flags in (T.TRT_FLAG_SPECULAR_KS, T.TRT_FLAG_SPECULAR_KS | T.TRT_FLAG_FIXED_NEE | T.TRT_FLAG_RAY_OFFSET, T.TRT_FLAG_SPECULAR_KS | T.TRT_FLAG_OVERLAP | T.TRT_FLAG_FIXED_PIXELS):
+        p = T.make_params(w, h, spp, 99, flags=flags)
+        img, st = r.render(p)
+        ref, ost = O.render(s.flat, p)
+        assert_same_image(img, ref, f"{name} flags {flags}")
+        assert st.rays == ost.rays
+
+
 def test_redo_path_is_counted_and_rare():
     """trt_stats.redo_rays: how many rays failed the check made when a result is stored and went through k_trace_fix.  On the shipped
     scenes that is a handful per ten million (with the bare `t < entry` rule of round 2 an unpadded tree sent a third of its rays there)."""

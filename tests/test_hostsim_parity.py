@@ -395,3 +395,25 @@ def test_equal_distance_hits_inside_one_large_leaf(tmp_path):
                 H.set_node_kind(old)
             assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1), (mats, leaf)
             s.close()
+
+
+@pytest.mark.parametrize("name", ["staircase", "veach-mis"])
+def test_specular_ks_flag_device_code_equals_oracle(name):
+    """TRT_FLAG_SPECULAR_KS (the look of the reference's own saved renders: a SPECULAR bounce weighted by Ks instead of the texel Kd): the device-side path functions
+    and both oracles apply the same switch.  staircase has the materials that tell the two weights apart (FloorTiles, Metal), veach-mis has Kd = Ks on every glossy
+    plate: there the flag must not change a bit."""
+    s = get_scene(name, 64, 36)
+    p = T.make_params(64, 36, 4, 21, flags=T.TRT_FLAG_SPECULAR_KS)
+    ref, st = O.render(s.flat, p)
+    img, rays = H.render(s.flat, p)
+    assert np.array_equal(img, ref) and rays == [st.rays_camera, st.rays_shadow, st.rays_indirect]
+    plain = O.render(s.flat, T.make_params(64, 36, 4, 21))[0]
+    assert np.array_equal(O.render(s.flat, p, mode=O.MODE_RECURSIVE)[0].shape, ref.shape)
+    if name == "veach-mis":
+        assert np.array_equal(ref, plain)
+    else:
+        assert not np.array_equal(ref, plain) and ref.mean() < plain.mean()
+        rec = O.render(s.flat, p, mode=O.MODE_RECURSIVE)[0]   # the literal recursion of shade() takes the same switch
+        assert np.allclose(rec, ref, rtol=2e-4, atol=1e-6)
+        lit = O.render_literal(s.flat, p)[0]                   # ... and so does the reference's own arithmetic
+        assert abs(lit.mean() / ref.mean() - 1.0) < 0.02

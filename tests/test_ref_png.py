@@ -228,7 +228,7 @@ def test_staircase_snapshots_weight_specular_bounces_by_ks():
     apart — FloorTiles (Ks 0.2 0.3 0.4 against a texel around 0.5-0.7: Kd returns more light, red most), Metal (Kd 0.2 grey, Ks 0 0.8 0.8: the
     strip by the door is TEAL in the snapshots and dark grey with Kd), Chrome (equal) — and no other shipped scene does (veach-mis: Kd = Ks on
     every glossy plate; back: no glossy material), which is why veach-mis sits on its noise floor either way.
-    With ORACLE_MODE_EXPERIMENT_SPECULAR_KS (an explicit oracle mode bit, test infrastructure; never the parity path) at image10.png's own
+    With TRT_FLAG_SPECULAR_KS (off by default: parity follows the committed source; the oracle, the literal oracle and the HIP path all take the switch) at image10.png's own
     10 spp the whole residual is gone: mean 1.0726 -> 0.9999 of the snapshot's, per channel 1.093 / 1.065 / 1.032 -> 1.000 / 1.000 / 1.000, median
     block error 5.6 % -> 2.3 % (the two-seed floor of this size is 2.2 %); at 256 spp against image256.png: 1.086 -> 0.9997, 5.7 % -> 0.69 %
     (full frame, measured once: 12 CPU-minutes).  Here: the lower 420 rows (the floor, the stairs, the strip) at 10 spp."""
@@ -241,8 +241,9 @@ def test_staircase_snapshots_weight_specular_bounces_by_ks():
     teal = (rb[..., 1] > 2.0 * rb[..., 0]) & (rb[..., 2] > 2.0 * rb[..., 0]) & (rb.sum(-1) > 0.05)  # the Metal strip as the snapshot shows it
     assert teal.sum() >= 1
     out = {}
-    for name, mode in (("committed", O.MODE_ITERATIVE), ("ks", O.MODE_ITERATIVE | O.MODE_EXPERIMENT_SPECULAR_KS)):
-        ob = _blocks(_lin8(T.tonemap(O.render(s.flat, p, mode=mode)[0])))
+    for name, flags in (("committed", 0), ("ks", T.TRT_FLAG_SPECULAR_KS)):   # (since round 4 a flag of the C-ABI too: the HIP path takes the same switch, GPU test below)
+        p.flags = flags
+        ob = _blocks(_lin8(T.tonemap(O.render(s.flat, p)[0])))
         ch = ob.mean((0, 1)) / rb.mean((0, 1))
         out[name] = (float(ob.mean() / rb.mean()), float(ch.max() / ch.min()), float(np.median(np.abs(ob - rb) / (0.02 + rb))), ob[teal].mean(0))
     (r_c, spread_c, med_c, teal_c), (r_k, spread_k, med_k, teal_k) = out["committed"], out["ks"]
@@ -312,6 +313,25 @@ def test_gpu_render_matches_the_references_own_snapshot(fixture, renderer_factor
     med_fixed, _, _ = _compare(fixed, png)
     print(f"{fixture}: with TRT_FLAG_FIXED_NEE: median block error {med_fixed:.4f}")
     assert med_fixed >= 0.15 and med_fixed >= 2.0 * med, (med, med_fixed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,spp,max_med", [("staircase_image10.png", 10, 0.03), ("staircase_image256.png", 256, 0.012)])
+def test_gpu_render_with_specular_ks_matches_the_staircase_snapshots_on_their_noise_floor(fixture, spp, max_med, renderer_factory):
+    """The product path end to end against the reference's own converged render: with TRT_FLAG_SPECULAR_KS — the one multiplication in which the revision behind the
+    staircase snapshots differs from the committed source — the HIP render at the snapshot's size and sample count matches it to the two-seed noise floor: six lights, three
+    JPEG textures, glass, the light-sampling quirks Q3-Q5, the pixel grid.  Measured (oracle): mean 0.9999 / 0.9997 of the snapshot's, every channel within 0.1 %, median
+    block error 2.3 % (floor 2.2 %) at 10 spp and 0.69 % at 256 spp.  Without the flag: 5.6 % / 5.7 % and 7-9 % brighter (test above)."""
+    png = _png(fixture)
+    h, w = png.shape[:2]
+    s = get_scene("staircase", w, h)
+    r = renderer_factory(s)
+    img, _ = r.render(T.make_params(w, h, spp, SEEDS["staircase"], flags=T.TRT_FLAG_SPECULAR_KS))
+    ob, rb = _blocks(_lin8(T.tonemap(img))), _blocks(_lin8(png))
+    ch = ob.mean((0, 1)) / rb.mean((0, 1))
+    med = float(np.median(np.abs(ob - rb) / (0.02 + rb)))
+    print(f"{fixture}: HIP {spp} spp with TRT_FLAG_SPECULAR_KS vs snapshot: mean {ob.mean() / rb.mean():.4f}, channels {np.round(ch, 4)}, median block error {med:.4f}")
+    assert abs(ob.mean() / rb.mean() - 1.0) <= 0.005 and ch.max() / ch.min() <= 1.005 and med <= max_med, (ob.mean() / rb.mean(), ch, med)
 
 
 @pytest.mark.gpu

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import Params, Stats, SceneFlat, TRT_FLAG_COUNT, TRT_FLAG_TIMING, TRT_FLAG_OVERLAP, TRT_FLAG_FIXED_NEE, TRT_FLAG_FIXED_PIXELS, TRT_FLAG_RAY_OFFSET, KERNEL_NAMES  # noqa: F401
+from ._abi import Params, Stats, SceneFlat, TRT_FLAG_COUNT, TRT_FLAG_TIMING, TRT_FLAG_OVERLAP, TRT_FLAG_FIXED_NEE, TRT_FLAG_FIXED_PIXELS, TRT_FLAG_RAY_OFFSET, TRT_FLAG_SPECULAR_KS, KERNEL_NAMES  # noqa: F401
 
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCENES_DIR = os.path.join(REPO_ROOT, "scenes")

@@ -18,6 +18,7 @@ TRT_FLAG_OVERLAP = 4
 TRT_FLAG_FIXED_NEE = 8
 TRT_FLAG_FIXED_PIXELS = 16
 TRT_FLAG_RAY_OFFSET = 32
+TRT_FLAG_SPECULAR_KS = 64
 TRT_MAX_KERNELS = 8
 KERNEL_NAMES = ["gen_primary", "trace_closest", "shade", "trace_shadow", "resolve", "tail"]
 

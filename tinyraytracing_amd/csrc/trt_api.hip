@@ -799,6 +799,7 @@ int renderCore(trt_handle* h, const trt_params* p, uint32_t s_begin, uint32_t s_
     td.fixed_nee = (p->flags & TRT_FLAG_FIXED_NEE) ? 1u : 0u;
     td.fixed_pixels = (p->flags & TRT_FLAG_FIXED_PIXELS) ? 1u : 0u;
     td.ray_offset = (p->flags & TRT_FLAG_RAY_OFFSET) ? 1u : 0u;
+    td.specular_ks = (p->flags & TRT_FLAG_SPECULAR_KS) ? 1u : 0u;
     td.npix_magic = magicOf(npix);
     td.tile_w_magic = magicOf(tw);
     td.grid_ok = (p->width >= 2 && p->height >= 2 && p->width <= 65536 && p->height <= 65536) ? 1u : 0u;

@@ -739,6 +739,7 @@ struct TileDesc {
     uint32_t fixed_nee;   // TRT_FLAG_FIXED_NEE
     uint32_t fixed_pixels;  // TRT_FLAG_FIXED_PIXELS
     uint32_t ray_offset;    // TRT_FLAG_RAY_OFFSET
+    uint32_t specular_ks;   // TRT_FLAG_SPECULAR_KS
     uint32_t npix;        // rows * tile_w
     uint32_t seed, spp;
     uint32_t npix_magic, tile_w_magic;  // magicOf(npix), magicOf(tile_w)
@@ -802,6 +803,7 @@ struct ShadeCtx {
     Vertex vx;
     const MaterialDev* m;  // into the scene's table (LDS copy inside k_shade): fields are fetched where they are used, not held in registers
     Stream rng;
+    bool spec_ks;   // TRT_FLAG_SPECULAR_KS: a SPECULAR bounce is weighted by the material's Ks instead of the texel Kd
     bool use_off;   // TRT_FLAG_RAY_OFFSET
     f3 off;         // eps * Ng of the hit triangle (only with use_off)
 };
@@ -836,6 +838,7 @@ TRT_HD inline void shadeBegin(const SceneDev& sc, const TileDesc& td, uint32_t s
     c.m = sc.materials;  // any valid record: only dereferenced under had_hit
     c.rng.key.k0 = c.rng.key.k1 = 0; c.rng.ctr = 0;
     c.use_off = td.ray_offset != 0u;
+    c.spec_ks = td.specular_ks != 0u;
     c.off = mk3(0, 0, 0);
     Hit h;
     h.t = hit4.x; h.tri = (int32_t)f2u(hit4.y); h.u = hit4.z; h.v = hit4.w; h.flags = 0;
@@ -883,7 +886,7 @@ TRT_HD inline void shadeNextFinish(const ShadeCtx& c, const NextPlan& pl, f4& ra
 {
     f3 nd;
     const int type = nextRayFinish(*c.m, c.vx.pn, c.d, pl, nd);
-    const f3 w = (type == TRT_RAY_TRANSMISSION) ? ld3(c.m->Tr) : c.vx.Kd;  // Q8: SPECULAR is weighted by Kd too
+    const f3 w = (type == TRT_RAY_TRANSMISSION) ? ld3(c.m->Tr) : ((c.spec_ks && type == TRT_RAY_SPECULAR) ? ld3(c.m->Ks) : c.vx.Kd);  // Q8: SPECULAR is weighted by Kd too (by Ks with TRT_FLAG_SPECULAR_KS)
     const f3 nb = (c.beta * w) / TRT_P_RR;
     const f3 org = rayOrigin(c, nd);  // Q6: the hit point itself unless TRT_FLAG_RAY_OFFSET
     ra = mk4(org.x, org.y, org.z, nd.x);

@@ -18,7 +18,7 @@ static void usage()
 {
     std::fprintf(stderr,
                  "usage: tinyrt <basedir> <mtl> <xml> <obj> <spp> [--width W --height H] [--seed S] [--device D | --gpus N | --devices a,b,..]\n"
-                 "              [--leaf N] [--gpu-bvh] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels] [--ray-offset] [--polygons]\n"
+                 "              [--leaf N] [--gpu-bvh] [--max-depth D] [--out file.png] [--fixed | --fixed-nee | --fixed-pixels] [--ray-offset] [--specular-ks] [--polygons]\n"
                  "              [--every N] [--checkpoint file.acc] [--stop-after M]\n"
                  "                                                    progressive: N samples per step, image rewritten after\n"
                  "                                                    every step, accumulator kept in file.acc (resumes from it)\n");
@@ -66,6 +66,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--fixed-nee")) opts.fixed_nee = true;
         else if (!std::strcmp(argv[i], "--fixed-pixels")) opts.fixed_pixels = true;
         else if (!std::strcmp(argv[i], "--ray-offset")) opts.ray_offset = true;
+        else if (!std::strcmp(argv[i], "--specular-ks")) opts.specular_ks = true;  // the look of the reference's own saved renders (TRT_FLAG_SPECULAR_KS)
         else if (!std::strcmp(argv[i], "--polygons")) polygons = true;
         else if (!std::strcmp(argv[i], "--fixed")) opts.fixed_nee = opts.fixed_pixels = true;
         else if (!std::strcmp(argv[i], "--every")) opts.every = std::atoi(need("--every"));

@@ -133,7 +133,7 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
     p.x0 = 0; p.y0 = 0; p.x1 = p.width; p.y1 = p.height;
     p.row_block = 1; p.row_mod = 1; p.row_rem = 0;
     p.max_depth = opts.max_depth;
-    p.flags = (opts.timing ? TRT_FLAG_TIMING : 0u) | (opts.overlap ? TRT_FLAG_OVERLAP : 0u) | (opts.fixed_nee ? TRT_FLAG_FIXED_NEE : 0u) | (opts.fixed_pixels ? TRT_FLAG_FIXED_PIXELS : 0u) | (opts.ray_offset ? TRT_FLAG_RAY_OFFSET : 0u);
+    p.flags = (opts.timing ? TRT_FLAG_TIMING : 0u) | (opts.overlap ? TRT_FLAG_OVERLAP : 0u) | (opts.fixed_nee ? TRT_FLAG_FIXED_NEE : 0u) | (opts.fixed_pixels ? TRT_FLAG_FIXED_PIXELS : 0u) | (opts.ray_offset ? TRT_FLAG_RAY_OFFSET : 0u) | (opts.specular_ks ? TRT_FLAG_SPECULAR_KS : 0u);
     p.mem_budget = opts.mem_budget;
     std::vector<float> out((size_t)p.width * p.height * 3);
     int rc = TRT_OK;
@@ -161,7 +161,7 @@ void render(Scene& scene, const RenderOpts& opts, double* image, trt_stats* stat
         // progressive: the accumulator lives on the host between calls (and in the checkpoint file)
         std::vector<double> accum(out.size(), 0.0);
         int done = 0;
-        const uint32_t est_flags = p.flags & (TRT_FLAG_FIXED_NEE | TRT_FLAG_FIXED_PIXELS | TRT_FLAG_RAY_OFFSET);
+        const uint32_t est_flags = p.flags & (TRT_FLAG_FIXED_NEE | TRT_FLAG_FIXED_PIXELS | TRT_FLAG_RAY_OFFSET | TRT_FLAG_SPECULAR_KS);
         const uint64_t scene_hash = opts.checkpoint.empty() ? 0ull : sceneHash(flat.c_scene());
         try {
             Checkpoint ck;

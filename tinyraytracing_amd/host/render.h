@@ -28,6 +28,7 @@ struct RenderOpts {
     bool overlap = true;      // two sample passes in flight (TRT_FLAG_OVERLAP)
     bool fixed_pixels = false;  // TRT_FLAG_FIXED_PIXELS: pixel-centred sampling grid instead of quirks Q1/Q2
     bool ray_offset = false;  // TRT_FLAG_RAY_OFFSET: rays start eps off the surface they leave instead of on it (quirk Q6)
+    bool specular_ks = false; // TRT_FLAG_SPECULAR_KS: SPECULAR bounces weighted by Ks, the look of the reference's own saved renders (include/trt.h)
     bool fixed_nee = false;   // TRT_FLAG_FIXED_NEE: unbiased light sampling + occlusion-test shadow rays instead of quirks Q3-Q5
     // Progressive output (trt_render_samples): render `every` samples per call (0 = all in one call), hand the
     // image so far to `on_progress`, and keep the accumulator in `checkpoint` (written after every call, atomically;

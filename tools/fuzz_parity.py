@@ -60,6 +60,7 @@ def main():
         if rng.random() < 0.4: flags |= T.TRT_FLAG_OVERLAP
         if rng.random() < 0.3: flags |= T.TRT_FLAG_COUNT
         if rng.random() < 0.3: flags |= T.TRT_FLAG_RAY_OFFSET
+        if rng.random() < 0.25: flags |= T.TRT_FLAG_SPECULAR_KS
         md = int(rng.choice([0, 0, 0, 1, 2, 5]))
         rows = None
         if rng.random() < 0.4:
