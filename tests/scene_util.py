@@ -136,3 +136,25 @@ def load_with_reference_tree(name, width=0, height=0, leaf_num=8):
     s._check(s._lib.trth_scene_adopt_bvh(s._h, nodes, n_nodes, perm.ctypes.data_as(C.POINTER(C.c_uint32)), depth))
     s._built = True
     return s
+
+
+def poison_geometry(scene, seed=5, every=40):
+    """Overwrites coordinates of the flat scene IN PLACE (after the BVH build: the tree keeps its boxes) with the values a careless exporter or a hostile caller of
+    the C-ABI can put there: NaN, +-inf, +-1e38 (squares overflow), a denormal, zero — about one vertex coordinate and one normal coordinate in `every` triangles
+    per value.  The reference's arithmetic absorbs them (a NaN fails every comparison: such a triangle is never hit, such a normal never lit); the test is that
+    oracle and device do so identically, and that no traversal or shading loop hangs on them.  Returns the number of overwritten floats."""
+    import ctypes as C
+
+    import numpy as np
+    f = scene.flat.contents
+    n = f.n_tris
+    v = np.ctypeslib.as_array(C.cast(f.tri_v, C.POINTER(C.c_float)), (n, 9))
+    vn = np.ctypeslib.as_array(C.cast(f.tri_vn, C.POINTER(C.c_float)), (n, 9))
+    rng = np.random.default_rng(seed)
+    count = 0
+    for val in (np.nan, np.inf, -np.inf, 1e38, -3e38, 1e-40, 0.0):
+        for arr in (v, vn):
+            for _ in range(max(1, n // every)):
+                arr[rng.integers(0, n), rng.integers(0, 9)] = val
+                count += 1
+    return count

@@ -417,3 +417,24 @@ def test_specular_ks_flag_device_code_equals_oracle(name):
         assert np.allclose(rec, ref, rtol=2e-4, atol=1e-6)
         lit = O.render_literal(s.flat, p)[0]                   # ... and so does the reference's own arithmetic
         assert abs(lit.mean() / ref.mean() - 1.0) < 0.02
+
+
+@pytest.mark.parametrize("name,leaf", [("back", 8), ("veach-mis", 2), ("veach-mis", 8)])
+def test_non_finite_geometry_is_absorbed_identically(name, leaf):
+    """NaN / inf / 1e38 / denormal coordinates and normals in the caller's arrays (scene_util.poison_geometry): the device code renders the oracle's image bit for
+    bit on both node kinds, and the image itself stays finite (a NaN fails every comparison of bvh.cpp:185-207 and pathTracing.cpp:60)."""
+    import scene_util as SU
+    s = T.Scene.named(name, 48, 48, leaf_num=leaf)
+    assert SU.poison_geometry(s) >= 14
+    p = T.make_params(48, 48, 4, 77)
+    ref, ost = O.render(s.flat, p)
+    assert np.isfinite(ref).all()
+    for nk in (0, 1):
+        old = H.set_node_kind(nk)
+        try:
+            img, rays = H.render(s.flat, p)
+        finally:
+            H.set_node_kind(old)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (name, leaf, nk)
+        assert rays == [ost.rays_camera, ost.rays_shadow, ost.rays_indirect]
+    s.close()

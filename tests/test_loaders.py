@@ -134,6 +134,52 @@ def test_jpeg_decoder_rejects_what_it_does_not_handle(tmp_path):
     assert lib.trth_decode_jpeg(os.fsencode(str(tmp_path / "missing.jpg")), C.byref(w), C.byref(h), None, 0) != 0
 
 
+def test_decoders_on_hostile_headers_and_coefficients(tmp_path):
+    """The two findings of tools/fuzz_decoders.py (mutation fuzzing under ASan + UBSan, ~1 M files): a header announcing an image the file cannot hold is
+    rejected BEFORE anything is allocated for it, and coefficients far outside what an encoder writes go through the inverse DCT in wrapping arithmetic
+    (tools/sanitize_cpu.sh runs this test under UBSan: no signed overflow)."""
+    import struct
+    import zlib
+    import time
+    lib = T._abi.load_host()
+    w, h = C.c_int(), C.c_int()
+    good = str(tmp_path / "g.jpg")
+    Image.fromarray(np.random.default_rng(3).integers(0, 256, (32, 32, 3), dtype=np.uint8)).save(good, quality=95, subsampling=0)
+    raw = bytearray(open(good, "rb").read())
+    sof = raw.index(b"\xff\xc0")
+    huge = bytearray(raw)
+    huge[sof + 5:sof + 9] = struct.pack(">HH", 65535, 65535)  # 4.3 G pixels in a 3 KB file
+    p = str(tmp_path / "huge.jpg")
+    open(p, "wb").write(bytes(huge))
+    t = time.time()
+    assert lib.trth_decode_jpeg(os.fsencode(p), C.byref(w), C.byref(h), None, 0) != 0
+    assert time.time() - t < 1.0
+    # every quantiser 255: the coefficients of a quality-95 file, times ~100
+    loud = bytearray(raw)
+    at = 0
+    while True:
+        at = loud.find(b"\xff\xdb", at)
+        if at < 0:
+            break
+        n = struct.unpack(">H", loud[at + 2:at + 4])[0]
+        for i in range(at + 5, at + 2 + n):
+            if (i - (at + 4)) % 65 != 0:
+                loud[i] = 255
+        at += 2 + n
+    p = str(tmp_path / "loud.jpg")
+    open(p, "wb").write(bytes(loud))
+    assert lib.trth_decode_jpeg(os.fsencode(p), C.byref(w), C.byref(h), None, 0) == 0 and (w.value, h.value) == (32, 32)
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 32768, 32768, 16, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(64))) + chunk(b"IEND", b"")
+    p = str(tmp_path / "huge.png")
+    open(p, "wb").write(png)
+    t = time.time()
+    assert lib.trth_decode_png(os.fsencode(p), C.byref(w), C.byref(h), None, 0) != 0
+    assert time.time() - t < 1.0
+
+
 def _decode_png(path):
     lib = T._abi.load_host()
     w, h = C.c_int(), C.c_int()

@@ -175,7 +175,9 @@ int trth_decode_jpeg(const char* path, int* width, int* height, uint8_t* rgb, ui
     if (!path || !width || !height) return fail("trth_decode_jpeg: null argument");
     std::vector<uint8_t> px;
     int w = 0, h = 0;
-    if (!trt::decodeJPEG(path, px, w, h)) return fail("trth_decode_jpeg: not a JPEG this decoder handles (8-bit Huffman, grey or YCbCr)");
+    try {
+        if (!trt::decodeJPEG(path, px, w, h)) return fail("trth_decode_jpeg: not a JPEG this decoder handles (8-bit Huffman, grey or YCbCr)");
+    } catch (const std::exception& e) { return fail(e); }
     *width = w;
     *height = h;
     if (rgb) {
@@ -190,7 +192,9 @@ int trth_decode_png(const char* path, int* width, int* height, uint8_t* rgb, uin
     if (!path || !width || !height) return fail("trth_decode_png: null argument");
     std::vector<uint8_t> px;
     int w = 0, h = 0;
-    if (!trt::decodePNG(path, px, w, h)) return fail("trth_decode_png: not a PNG this decoder handles");
+    try {
+        if (!trt::decodePNG(path, px, w, h)) return fail("trth_decode_png: not a PNG this decoder handles");
+    } catch (const std::exception& e) { return fail(e); }
     *width = w;
     *height = h;
     if (rgb) {

@@ -95,7 +95,22 @@ const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4
                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 inline uint8_t clampSample(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
-inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// 32-bit two's-complement arithmetic that WRAPS: what libjpeg's INT32 code does in every build of it on out-of-range coefficients (a corrupt or hostile
+// file can hold any 16-bit value times any quantiser), spelled so that it is defined behaviour here.  Identical to plain int32_t wherever nothing overflows,
+// i.e. on every valid file.
+struct w32 {
+    uint32_t v;
+    w32() = default;
+    w32(int32_t x) : v((uint32_t)x) {}
+    static w32 raw(uint32_t u) { w32 r; r.v = u; return r; }
+    friend w32 operator+(w32 a, w32 b) { return raw(a.v + b.v); }
+    friend w32 operator-(w32 a, w32 b) { return raw(a.v - b.v); }
+    friend w32 operator*(w32 a, w32 b) { return raw(a.v * b.v); }
+    w32& operator+=(w32 b) { v += b.v; return *this; }
+    w32& operator*=(w32 b) { v *= b.v; return *this; }
+};
+inline int32_t descale(w32 x, int n) { return (int32_t)(x.v + (1u << (n - 1))) >> n; }
 
 // libjpeg jidctint.c (JDCT_ISLOW): Loeffler-Ligtenberg-Moschytz, CONST_BITS = 13, PASS1_BITS = 2.
 void idctIslow(const int32_t* coef, uint8_t* out, int stride)
@@ -103,45 +118,45 @@ void idctIslow(const int32_t* coef, uint8_t* out, int stride)
     constexpr int CB = 13, P1 = 2;
     constexpr int32_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137, F1961 = 16069,
                       F2053 = 16819, F2562 = 20995, F3072 = 25172;
-    int32_t ws[64];
+    w32 ws[64];
     for (int c = 0; c < 8; ++c) {
         const int32_t* in = coef + c;
-        int32_t z2 = in[16], z3 = in[48];
-        int32_t z1 = (z2 + z3) * F0541;
-        int32_t tmp2 = z1 + z3 * (-F1847);
-        int32_t tmp3 = z1 + z2 * F0765;
-        z2 = in[0];
-        z3 = in[32];
-        int32_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-        tmp0 = in[56]; tmp1 = in[40]; tmp2 = in[24]; tmp3 = in[8];
+        w32 z2 = w32(in[16]), z3 = w32(in[48]);
+        w32 z1 = (z2 + z3) * w32(F0541);
+        w32 tmp2 = z1 + z3 * w32(-F1847);
+        w32 tmp3 = z1 + z2 * w32(F0765);
+        z2 = w32(in[0]);
+        z3 = w32(in[32]);
+        w32 tmp0 = (z2 + z3) * w32(1 << CB), tmp1 = (z2 - z3) * w32(1 << CB);
+        const w32 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = w32(in[56]); tmp1 = w32(in[40]); tmp2 = w32(in[24]); tmp3 = w32(in[8]);
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * F1175;
-        tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
-        z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+        w32 z4 = tmp1 + tmp3;
+        const w32 z5 = (z3 + z4) * w32(F1175);
+        tmp0 *= w32(F0298); tmp1 *= w32(F2053); tmp2 *= w32(F3072); tmp3 *= w32(F1501);
+        z1 *= w32(-F0899); z2 *= w32(-F2562); z3 *= w32(-F1961); z4 *= w32(-F0390);
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-        ws[c] = descale(tmp10 + tmp3, CB - P1);       ws[56 + c] = descale(tmp10 - tmp3, CB - P1);
-        ws[8 + c] = descale(tmp11 + tmp2, CB - P1);   ws[48 + c] = descale(tmp11 - tmp2, CB - P1);
-        ws[16 + c] = descale(tmp12 + tmp1, CB - P1);  ws[40 + c] = descale(tmp12 - tmp1, CB - P1);
-        ws[24 + c] = descale(tmp13 + tmp0, CB - P1);  ws[32 + c] = descale(tmp13 - tmp0, CB - P1);
+        ws[c] = w32(descale(tmp10 + tmp3, CB - P1));       ws[56 + c] = w32(descale(tmp10 - tmp3, CB - P1));
+        ws[8 + c] = w32(descale(tmp11 + tmp2, CB - P1));   ws[48 + c] = w32(descale(tmp11 - tmp2, CB - P1));
+        ws[16 + c] = w32(descale(tmp12 + tmp1, CB - P1));  ws[40 + c] = w32(descale(tmp12 - tmp1, CB - P1));
+        ws[24 + c] = w32(descale(tmp13 + tmp0, CB - P1));  ws[32 + c] = w32(descale(tmp13 - tmp0, CB - P1));
     }
     for (int r = 0; r < 8; ++r) {
-        const int32_t* w = ws + r * 8;
+        const w32* w = ws + r * 8;
         uint8_t* o = out + r * stride;
-        int32_t z2 = w[2], z3 = w[6];
-        int32_t z1 = (z2 + z3) * F0541;
-        int32_t tmp2 = z1 + z3 * (-F1847);
-        int32_t tmp3 = z1 + z2 * F0765;
-        int32_t tmp0 = (w[0] + w[4]) * (1 << CB), tmp1 = (w[0] - w[4]) * (1 << CB);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        w32 z2 = w[2], z3 = w[6];
+        w32 z1 = (z2 + z3) * w32(F0541);
+        w32 tmp2 = z1 + z3 * w32(-F1847);
+        w32 tmp3 = z1 + z2 * w32(F0765);
+        w32 tmp0 = (w[0] + w[4]) * w32(1 << CB), tmp1 = (w[0] - w[4]) * w32(1 << CB);
+        const w32 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * F1175;
-        tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
-        z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+        w32 z4 = tmp1 + tmp3;
+        const w32 z5 = (z3 + z4) * w32(F1175);
+        tmp0 *= w32(F0298); tmp1 *= w32(F2053); tmp2 *= w32(F3072); tmp3 *= w32(F1501);
+        z1 *= w32(-F0899); z2 *= w32(-F2562); z3 *= w32(-F1961); z4 *= w32(-F0390);
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
         constexpr int S = CB + P1 + 3;
@@ -508,6 +523,12 @@ bool decodeJPEG(const std::string& path, std::vector<uint8_t>& rgb, int& width, 
             width = (seg[3] << 8) | seg[4];
             const int nc = seg[5];
             if ((nc != 1 && nc != 3) || seglen < (size_t)(6 + 3 * nc) || width <= 0 || height <= 0) return false;
+            // A header may claim any size up to 65535 x 65535; every 8x8 block of it costs at least one bit of entropy-coded data (its DC code), so a file
+            // shorter than that cannot hold the image it announces — rejected before anything is allocated for it.  (+ a cap of 2^28 pixels.)
+            {
+                const uint64_t blocks = (((uint64_t)width + 7) / 8) * (((uint64_t)height + 7) / 8);
+                if ((uint64_t)width * (uint64_t)height > (1ull << 28) || blocks / 8 > data.size()) return false;
+            }
             comps.resize((size_t)nc);
             for (int c = 0; c < nc; ++c) {
                 comps[c].id = seg[6 + 3 * c];

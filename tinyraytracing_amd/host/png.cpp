@@ -259,6 +259,9 @@ bool decodePNG(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
         stride[k] = (pw[k] * (size_t)bits_pp + 7) / 8;
         if (pw[k] && ph[k]) total += ph[k] * (stride[k] + 1);
     }
+    // deflate expands by less than 1032 : 1 (a 258-byte match per 2 bits): a stream too short for the scanlines the header announces is rejected before
+    // anything is allocated for them.  (+ a cap of 2^28 pixels.)
+    if ((uint64_t)w * h > (1ull << 28) || total / 1032 > idat.size()) return false;
     std::vector<uint8_t> raw;
     if (!inflate(idat.data(), idat.size(), raw, total)) return false;
     rgb.assign((size_t)w * h * 3, 0);
