@@ -63,6 +63,21 @@ def adversarial_rays(scene, n, seed=31):
     return org, d
 
 
+def non_finite_rays(scene, n, seed=3):
+    """Rays a caller of trt_trace_closest can hand over but no camera produces: NaN, +-inf, +-1e38, a denormal or a signed zero in one coordinate of the origin
+    (every third ray) or of the direction (every second), and the zero vector as a direction (every fiftieth)."""
+    lo, hi = scene_bounds(scene)
+    org, d = random_rays(n, lo, hi, seed=seed)
+    rng = np.random.default_rng(seed)
+    vals = np.array([np.nan, np.inf, -np.inf, 1e38, -1e38, 3e-39, 0.0, -0.0], np.float32)
+    k = np.arange(n)
+    for arr, m in ((org, 3), (d, 2)):
+        sel = (k % m) == 0
+        arr[sel, rng.integers(0, 3, sel.sum())] = vals[rng.integers(0, len(vals), sel.sum())]
+    d[k % 50 == 0] = 0.0
+    return org, d
+
+
 def grazing_rays(flat, n, seed=5):
     """Rays that meet a random triangle of the scene at 1e-5 .. 1e-2 rad from its plane, from 0.1 .. 16 units away: the rays for which a
     Moller-Trumbore distance is least accurate (the case behind the rule 'a hit in front of its own leaf's box does not count')."""

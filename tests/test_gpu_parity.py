@@ -891,3 +891,18 @@ def test_non_finite_geometry_is_absorbed_identically(name, leaf, nk, monkeypatch
     assert_same_image(img, ref, f"{name} leaf {leaf} node kind {nk}, poisoned")
     assert st.rays == ost.rays
     s.close()
+
+
+@pytest.mark.parametrize("name,impl,nk", [("back", "0", "0"), ("back", "3", "1"), ("veach-mis", "3", "0"), ("veach-mis", "3", "1"), ("staircase", "3", "1")])
+def test_non_finite_rays_find_what_the_oracle_finds(name, impl, nk, monkeypatch):
+    """trt_trace_closest on NaN / inf / 1e38 / denormal origins and directions and on zero directions (raygen.non_finite_rays): every launch ends, and the
+    answer is the oracle's — same triangle, same bits of t and (u, v) — on the wave-uniform walk of a tiny tree and on both node kinds of the persistent kernels."""
+    monkeypatch.setenv("TRT_TRACE_IMPL", impl)
+    monkeypatch.setenv("TRT_NODE_KIND", nk)
+    s = get_scene(name, 64, 36)
+    org, dirs = raygen.non_finite_rays(s, 200000)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    r = T.Renderer(s, 0)
+    t1, tri1, uv1 = r.trace_closest(org, dirs)
+    r.close()
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(uv0.view(np.uint32), uv1.view(np.uint32))

@@ -438,3 +438,19 @@ def test_non_finite_geometry_is_absorbed_identically(name, leaf):
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (name, leaf, nk)
         assert rays == [ost.rays_camera, ost.rays_shadow, ost.rays_indirect]
     s.close()
+
+
+@pytest.mark.parametrize("name", ["back", "veach-mis", "staircase"])
+def test_non_finite_rays_find_what_the_oracle_finds(name):
+    """NaN / inf / 1e38 / denormal origins and directions, zero directions (raygen.non_finite_rays): same triangle, same bits of t and (u, v), both node kinds."""
+    s = get_scene(name, 64, 36)
+    org, dirs = raygen.non_finite_rays(s, 30000)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    assert (tri0 >= 0).sum() > 3000
+    for nk in (0, 1):
+        old = H.set_node_kind(nk)
+        try:
+            t1, tri1, uv1, _ = H.trace(s.flat, org, dirs)
+        finally:
+            H.set_node_kind(old)
+        assert np.array_equal(tri0, tri1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(uv0.view(np.uint32), uv1.view(np.uint32)), (name, nk)
