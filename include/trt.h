@@ -55,6 +55,9 @@ extern "C" {
  *                                bits 26..0  = first triangle (post-BVH order).
  * Post-BVH order (what bvh.cpp's in-place sort leaves behind): every triangle under child0 has a lower index than
  * every triangle under child1; trt_create checks it (the tie rule of bvh.cpp:168-172 is applied by index).
+ * Boxes: any finite coordinates or +-inf, nested or not (a subtree is entered iff the ray passes its stored box, bvh.cpp:162-166, whatever the boxes above
+ * or below it say); a NaN coordinate is refused by trt_create (TRT_EINVAL): glm::min / glm::max pass a NaN on from their first operand only, so the reference's
+ * own answer on such a box depends on the axis the NaN sits on.
  * Leaf size: any tree with leaves of 1..15 triangles is walked by the same kernels and gives the reference's hits on THAT tree.  As in the reference
  * (bvh.cpp:151-154) every triangle of a leaf is tested whenever the ray passes the leaf's box, so large leaves cost tests: the reference's own
  * buildBVH(..., 8) tree runs at about 0.8 of the speed of a tree built with 2 (every published number is on leaf 2). */

@@ -113,16 +113,68 @@ def test_trt_create_validates_the_bvh_before_touching_a_device():
     nodes = (BvhNode * f.n_nodes)()
     g.nodes = nodes
     h = C.c_void_p()
-    for what, needle in (("index", b"out of range"), ("cycle", b"twice"), ("order", b"post-BVH order")):
+    for what, needle in (("index", b"out of range"), ("cycle", b"twice"), ("order", b"post-BVH order"), ("nan", b"NaN")):
         C.memmove(nodes, f.nodes, C.sizeof(BvhNode) * f.n_nodes)
         if what == "index":
             nodes[3].child1 = 0x7FFFFFF0
+        elif what == "nan":
+            nodes[7].hi1[1] = float("nan")
         elif what == "cycle":
             nodes[5].child0 = 0
         else:
             nodes[0].child0, nodes[0].child1 = f.nodes[0].child1, f.nodes[0].child0
         assert lib.trt_create(C.byref(g), 0, C.byref(h)) == 1
         assert needle in lib.trt_last_error(), (what, lib.trt_last_error())
+
+
+def test_random_damage_to_a_tree_is_refused_or_harmless():
+    """400 random mutations of the caller's node array (child words replaced by random bits, by other nodes' words, leaf counts and first indices nudged,
+    boxes made NaN / inverted): trt_create answers each with TRT_EINVAL and a message, or — where the damage leaves a tree the rules accept (a box is not
+    a rule: foreign boxes need not nest) — goes on to the device; it never crashes, loops or reads outside the arrays."""
+    import numpy as np
+    import tinyraytracing_amd as T
+    from tinyraytracing_amd._abi import BvhNode, SceneFlat
+    lib = _abi.load_hip()
+    s = T.Scene.named("veach-mis", 32, 18)
+    f = s.flat.contents
+    g = SceneFlat()
+    C.memmove(C.byref(g), C.byref(f), C.sizeof(SceneFlat))
+    nodes = (BvhNode * f.n_nodes)()
+    g.nodes = nodes
+    words = np.ctypeslib.as_array(C.cast(nodes, C.POINTER(C.c_uint32)), (f.n_nodes, C.sizeof(BvhNode) // 4))
+    floats = words.view(np.float32)
+    child_cols = [BvhNode.child0.offset // 4, BvhNode.child1.offset // 4]
+    rng = np.random.default_rng(11)
+    h = C.c_void_p()
+    refused = 0
+    for it in range(400):
+        C.memmove(nodes, f.nodes, C.sizeof(BvhNode) * f.n_nodes)
+        for _ in range(int(rng.integers(1, 4))):
+            n, c = int(rng.integers(0, f.n_nodes)), child_cols[int(rng.integers(0, 2))]
+            k = int(rng.integers(0, 6))
+            if k == 0:
+                words[n, c] = rng.integers(0, 2**32, dtype=np.uint64).astype(np.uint32)
+            elif k == 1:
+                words[n, c] = words[int(rng.integers(0, f.n_nodes)), child_cols[int(rng.integers(0, 2))]]
+            elif k == 2:
+                words[n, c] ^= np.uint32(1 << int(rng.integers(0, 32)))
+            elif k == 3:
+                words[n, c] = np.uint32((int(words[n, c]) + int(rng.integers(-3, 4))) & 0xFFFFFFFF)
+            elif k == 4:
+                col = int(rng.integers(0, words.shape[1]))
+                if col not in child_cols:
+                    floats[n, col] = [np.nan, np.inf, -np.inf, 1e38, -1e38][int(rng.integers(0, 5))]
+            else:
+                words[n, child_cols[0]], words[n, child_cols[1]] = words[n, child_cols[1]], words[n, child_cols[0]]
+        rc = lib.trt_create(C.byref(g), 0, C.byref(h))
+        assert rc != 0 or h.value
+        if rc == 0:
+            lib.trt_destroy(h)
+        else:
+            assert lib.trt_last_error()
+            refused += b"HIP device" not in lib.trt_last_error() and b"gfx950" not in lib.trt_last_error()
+    assert refused > 200
+    s.close()
 
 
 def test_validation_on_several_host_threads_finds_faults_deep_in_a_big_tree(monkeypatch):

@@ -875,13 +875,14 @@ def test_trace_grazing_rays_on_every_node_kind(name, monkeypatch):
         assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1), (name, nk)
 
 
-@pytest.mark.parametrize("name,leaf,nk", [("back", 8, "0"), ("veach-mis", 2, "1"), ("veach-mis", 8, "1"), ("staircase", 2, "0"), ("staircase", 2, "1")])
-def test_non_finite_geometry_is_absorbed_identically(name, leaf, nk, monkeypatch):
+@pytest.mark.parametrize("name,leaf,nk,boxes", [("back", 8, "0", False), ("veach-mis", 2, "1", False), ("veach-mis", 8, "1", False), ("staircase", 2, "0", False),
+                                                ("staircase", 2, "1", False), ("veach-mis", 2, "1", True), ("staircase", 8, "1", True)])
+def test_non_finite_geometry_is_absorbed_identically(name, leaf, nk, boxes, monkeypatch):
     """The kernels on NaN / inf / 1e38 / denormal coordinates and normals (scene_util.poison_geometry, written into the caller's arrays before trt_create): every
     launch ends (the traversal is a walk over a validated topology, whatever the numbers say), and the image is the oracle's bit for bit."""
     monkeypatch.setenv("TRT_NODE_KIND", nk)
     s = T.Scene.named(name, 96, 54, leaf_num=leaf)
-    SU.poison_geometry(s)
+    SU.poison_geometry(s, boxes=boxes)  # boxes: +-inf / +-1e38 in the tree's boxes too (the handle then keeps the exact 4-wide nodes)
     p = T.make_params(96, 54, 4, 77)
     ref, ost = O.render(s.flat, p)
     r = T.Renderer(s, 0)

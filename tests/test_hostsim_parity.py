@@ -419,13 +419,13 @@ def test_specular_ks_flag_device_code_equals_oracle(name):
         assert abs(lit.mean() / ref.mean() - 1.0) < 0.02
 
 
-@pytest.mark.parametrize("name,leaf", [("back", 8), ("veach-mis", 2), ("veach-mis", 8)])
-def test_non_finite_geometry_is_absorbed_identically(name, leaf):
+@pytest.mark.parametrize("name,leaf,boxes", [("back", 8, False), ("veach-mis", 2, False), ("veach-mis", 8, False), ("veach-mis", 2, True), ("staircase", 8, True)])
+def test_non_finite_geometry_is_absorbed_identically(name, leaf, boxes):
     """NaN / inf / 1e38 / denormal coordinates and normals in the caller's arrays (scene_util.poison_geometry): the device code renders the oracle's image bit for
     bit on both node kinds, and the image itself stays finite (a NaN fails every comparison of bvh.cpp:185-207 and pathTracing.cpp:60)."""
     import scene_util as SU
     s = T.Scene.named(name, 48, 48, leaf_num=leaf)
-    assert SU.poison_geometry(s) >= 14
+    assert SU.poison_geometry(s, boxes=boxes) >= 14  # boxes: +-inf / +-1e38 in the tree's boxes too (it then keeps the exact 4-wide nodes)
     p = T.make_params(48, 48, 4, 77)
     ref, ost = O.render(s.flat, p)
     assert np.isfinite(ref).all()

@@ -178,6 +178,14 @@ int validateBvh(const trt_scene* s, uint32_t* depth_out, unsigned threads = 1)
         if (ni >= nn) return "bvh: child index out of range";
         if (seen[ni].exchange(1, std::memory_order_relaxed)) return "bvh: node reachable twice";
         if (dep > MAX_BVH_DEPTH) return "bvh: deeper than 256 levels";
+        // A NaN box coordinate is refused: glm::min / glm::max (bvh.cpp:238-242) let a NaN through from their FIRST operand only, so what such a box does to a ray
+        // depends on the axis it sits on — a behaviour nobody builds on, and one the kernels' v_min / v_max (which drop a NaN from either side) would have to pay
+        // two instructions per slab to mimic.  +-inf and every finite value, nested or not, are fine (tests: poisoned geometry; boxes that do not nest).
+        {
+            const trt_bvh_node& nd = s->nodes[ni];
+            for (int a = 0; a < 3; ++a)
+                if (nd.lo0[a] != nd.lo0[a] || nd.hi0[a] != nd.hi0[a] || nd.lo1[a] != nd.lo1[a] || nd.hi1[a] != nd.hi1[a]) return "bvh: a box coordinate is NaN";
+        }
         const uint32_t ch[2] = {s->nodes[ni].child0, s->nodes[ni].child1};
         for (uint32_t c : ch) {
             if (c & TRT_LEAF_BIT) {
