@@ -5,6 +5,7 @@
 // bit-for-bit against the oracle on a machine without a GPU.  It is not a render
 // back end: nothing in the product loads this library.
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "trt_path.h"
@@ -79,6 +80,7 @@ struct HostScene {
         light_boxes = lightBoxesOf(leaf_boxes, s->tri_mat, s->n_tris, s->lights, s->n_lights);
         sc.leaf_box = leaf_boxes.data();
         sc.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
+        sc.cull_alpha = wide_detail::boxesNested(s->nodes, s->n_nodes) ? sc.leaf_alpha : std::numeric_limits<float>::infinity();  // as trt_create
         nk = (oct.ok && g_node_kind != 0) ? 1 : 0;
         sc.tri_isect = isect.data();
         sc.tri_shade = shade.data();

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <limits>
 #include <chrono>
 #include <cstring>
 #include <condition_variable>
@@ -393,6 +394,8 @@ struct SceneImage {
     std::vector<TextureDev> tex;
     std::vector<uint8_t> tex_bytes;
     float leaf_alpha = 0.0f;
+    float cull_alpha = 0.0f;  // leaf_alpha, or +inf for a tree whose boxes do not nest (SceneDev::cull_alpha)
+    bool nested = true;
 };
 
 struct Lap {  // TRT_DEBUG: where the start-up time of a big scene goes (tools/create_cost.py)
@@ -470,6 +473,10 @@ int buildSceneImage(const trt_scene* s, SceneImage& im)
     if (const char* e = std::getenv("TRT_SHADOW_STOP"))  // 0: all of space as every light's box, i.e. no early end of a shadow ray (A/B)
         if (std::atoi(e) == 0) im.light_boxes.assign(s->n_lights, LightBox{{-3.0e38f, -3.0e38f, -3.0e38f}, {3.0e38f, 3.0e38f, 3.0e38f}});
     im.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
+    // Culling by distance rests on nested boxes; a foreign tree that breaks the premise is walked without it (every box the ray passes is entered, bvh.cpp:162-166)
+    im.nested = wide_detail::boxesNested(s->nodes, s->n_nodes, im.threads);
+    im.cull_alpha = im.nested ? im.leaf_alpha : std::numeric_limits<float>::infinity();
+    if (im.dbg && !im.nested) std::fprintf(stderr, "[trt] the boxes of this tree do not nest: traversal without distance culling\n");
     lap("leaf boxes, light boxes");
     // The 8-wide compressed nodes (trt_oct.h) for the persistent traversal kernels, when the tree qualifies (nested, finite; larger
     // leaves are laid out as several slots with the leaf's own box): TRT_NODE_KIND=0/1 in the environment forces either kind (A/B runs, tests).
@@ -578,6 +585,7 @@ int createOnDevice(const SceneImage& im, int device, trt_handle** out)
     h->sc.n_lights = s->n_lights;
     h->sc.light0_area = s->n_lights ? s->lights[0].area : 0.0f;
     h->sc.leaf_alpha = im.leaf_alpha;
+    h->sc.cull_alpha = im.cull_alpha;
     h->sc.cam = s->camera;
     for (uint32_t i = 0; i < s->n_lights; ++i) h->light_mats.push_back((uint32_t)s->lights[i].mat);
     {   // which small tables k_shade copies into LDS: in this order while they fit (uploads are padded to 16 B)

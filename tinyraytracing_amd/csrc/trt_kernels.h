@@ -475,7 +475,7 @@ __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const R
             // ---- inner-node step
             if (is_inner) {
                 if (COUNT) { pr.n_inner++; if (lane == (uint32_t)__ffsll((long long)m_in) - 1u) pr.wave_inner++; }
-                if (innerStep(sc, cur, sp, stk, o, inv, trt_cull_bound(best_t, sc.leaf_alpha))) { lk = 0; lt = TRT_INF; li = -1; }
+                if (innerStep(sc, cur, sp, stk, o, inv, trt_cull_bound(best_t, sc.cull_alpha))) { lk = 0; lt = TRT_INF; li = -1; }
                 else adv = true;
             }
         } else {

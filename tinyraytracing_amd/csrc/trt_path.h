@@ -146,6 +146,7 @@ struct SceneDev {
     uint32_t leaf_loop;   // oct driver: triangles a lane tests per leaf step (trt_kernels.h; 2 for trees with leaves of <= 3, more where the caller's leaves are larger)
     float light0_area;  // Q3: every light's CDF draw spans lights[0].area (pathTracing.cpp:38)
     float leaf_alpha;   // absolute part of the leaf-box rule's tolerance (trt_leaf_floor, trt_prims.h): sceneLeafAlpha()
+    float cull_alpha;   // what trt_cull_bound() gets on the 4-wide nodes: leaf_alpha where the boxes of the tree nest, +inf (never cull by distance) where they do not (trt_wide.h boxesNested)
     trt_camera cam;
 };
 
@@ -461,7 +462,7 @@ TRT_HD inline Hit traceClosestPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, u
             continue;
         }
         if (COUNT) n_inner++;
-        if (!innerStep(sc, cur, sp, stk, o, inv, trt_cull_bound(best.t, sc.leaf_alpha))) {
+        if (!innerStep(sc, cur, sp, stk, o, inv, trt_cull_bound(best.t, sc.cull_alpha))) {
             if (sp == 0) break;
             cur = stk.pop(--sp);
         }

@@ -92,10 +92,12 @@ inline double halfAreaD(const Box& b)
     const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2];
     return dx * dy + dy * dz + dz * dx;
 }
+// Containment as the slab test sees the boxes: interactAABB (bvh.cpp:231-245) takes min / max of the two planes of an axis, so a box stored with lo > hi
+// IS the box [hi, lo] to every ray; compared raw, an inverted parent could "contain" a child that reaches outside it.
 inline bool contains(const Box& p, const Box& c)
 {
     for (int a = 0; a < 3; ++a)
-        if (!(p.lo[a] <= c.lo[a] && p.hi[a] >= c.hi[a])) return false;
+        if (!(std::fmin(p.lo[a], p.hi[a]) <= std::fmin(c.lo[a], c.hi[a]) && std::fmax(p.lo[a], p.hi[a]) >= std::fmax(c.lo[a], c.hi[a]))) return false;
     return true;
 }
 inline void children(const trt_bvh_node& n, Entry out[2])
@@ -107,6 +109,11 @@ inline void children(const trt_bvh_node& n, Entry out[2])
     out[0].ref = n.child0;
     out[1].ref = n.child1;
 }
+// Do the boxes of the tree nest — does every stored box of an inner child contain the two boxes stored in that child?  The premise of culling by distance
+// (trt_path.h, "the rule is what makes culling exact": floor(entry of a leaf's box) >= floor(entry of every box above it)).  A foreign tree may break it
+// (include/trt.h accepts any boxes); such a tree is walked WITHOUT distance culling (SceneDev::cull_alpha = +inf), i.e. exactly as bvh.cpp:146-175 walks it.
+// Nodes no path reaches are looked at too: a "no" because of one of them costs speed, never correctness.
+inline bool boxesNested(const trt_bvh_node* nodes, uint32_t n_nodes, unsigned threads = 1);
 
 // The binary tree cut for parallel work: `top` = the inner nodes above the cut, parents before children; `roots` = the inner nodes
 // on the cut, each the root of a subtree one task walks on its own.  One thread: the cut is the root itself.
@@ -264,6 +271,24 @@ inline void emitWide(const trt_bvh_node* nodes, unsigned threads, Expand expand,
         w.dropped += t.dropped;
     }
 }
+inline bool boxesNested(const trt_bvh_node* nodes, uint32_t n_nodes, unsigned threads)
+{
+    std::atomic<bool> ok{true};
+    par::forRange(n_nodes, threads ? threads : 1, 65536, [&](size_t n0, size_t n1) {
+        for (size_t n = n0; n < n1 && ok.load(std::memory_order_relaxed); ++n) {
+            Entry c[2];
+            children(nodes[n], c);
+            for (int k = 0; k < 2; ++k) {
+                if ((c[k].ref & TRT_LEAF_BIT) || c[k].ref >= n_nodes) continue;
+                Entry g[2];
+                children(nodes[c[k].ref], g);
+                if (!contains(c[k].b, g[0].b) || !contains(c[k].b, g[1].b)) { ok.store(false, std::memory_order_relaxed); break; }
+            }
+        }
+    });
+    return ok.load();
+}
+
 }  // namespace wide_detail
 
 // `nodes` must have passed validateBvh (every inner node reachable exactly once, indices in range).

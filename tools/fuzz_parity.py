@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak: random tiles / row interleaves / spp / seeds / flags / depth caps / memory budgets of the three cg22
-scenes (and a 50 k-triangle soup) rendered by the HIP path through the C-ABI — default handles, handles on trees of the GPU builder, and handles on the optional code paths
+scenes (and a 50 k-triangle soup) rendered by the HIP path through the C-ABI — default handles, handles on trees of the GPU builder, on the reference's own leaf size, on hostile
+trees (boxes that do not nest, +-inf, inverted; non-finite vertices and normals), and handles on the optional code paths
 (quantised nodes, speculative scheduler, per-lane traversal of the tiny scene) — and by the oracle; every image and every ray count
 must be identical.  usage: tools/fuzz_parity.py [seconds] [seed]"""
 import os
@@ -21,7 +22,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sizes = {"back": (257, 131), "veach-mis": (320, 180), "staircase": (192, 108), "soup": (160, 90)}
-    scenes, renderers, alt, scenes_gpu_tree, on_gpu_tree, scenes_leaf8, on_leaf8 = {}, {}, {}, {}, {}, {}, {}
+    scenes, renderers, alt, scenes_gpu_tree, on_gpu_tree, scenes_leaf8, on_leaf8, scenes_foreign, on_foreign = {}, {}, {}, {}, {}, {}, {}, {}, {}
     for name, (w, h) in sizes.items():
         scenes[name] = T.Scene.named(name, w, h, **({"n": 50000} if name == "soup" else {}))
         renderers[name] = T.Renderer(scenes[name], 0)
@@ -35,6 +36,14 @@ def main():
         os.environ["TRT_TRACE_IMPL"] = "3"
         on_leaf8[name] = T.Renderer(scenes_leaf8[name], 0)
         del os.environ["TRT_TRACE_IMPL"]
+        # a fifth handle per scene on a HOSTILE tree (what the C-ABI accepts and no builder emits): boxes pulled in so that they no longer contain what lies below
+        # them, +-inf / +-1e38 box coordinates (some of them inverting a box), NaN / inf / 1e38 vertices and normals — the kernels then walk the exact 4-wide
+        # nodes without distance culling (trt_wide.h boxesNested); the oracle walks the same arrays
+        scenes_foreign[name] = T.Scene.named(name, w, h, leaf_num=int(rng.choice([2, 8])), **({"n": 50000} if name == "soup" else {}))
+        if scenes_foreign[name].flat.contents.n_nodes > 40:
+            SU.shrink_some_boxes(scenes_foreign[name], max(4, scenes_foreign[name].flat.contents.n_nodes // 40), seed=int(rng.integers(0, 1000)))
+        SU.poison_geometry(scenes_foreign[name], seed=int(rng.integers(0, 1000)), every=200, boxes=True)
+        on_foreign[name] = T.Renderer(scenes_foreign[name], 0)
         # a second handle per scene on the OTHER node kind of the traversal kernels (exact 4-wide nodes where the default is the 8-wide
         # compressed ones), and per-lane traversal instead of the uniform walk for the tiny scene
         os.environ["TRT_NODE_KIND"] = "0"
@@ -71,18 +80,18 @@ def main():
         if not T.rows_selected(p):
             continue
         pick = rng.random()
-        use = on_gpu_tree if pick < 0.2 else (alt if pick < 0.45 else (on_leaf8 if pick < 0.7 else renderers))
+        use = on_gpu_tree if pick < 0.2 else (alt if pick < 0.4 else (on_leaf8 if pick < 0.6 else (on_foreign if pick < 0.75 else renderers)))
         try:
             img, st = use[name].render(p)
         except T.TrtError as e:
             if "mem_budget too small" in str(e):
                 continue
             raise
-        ref, ost = O.render((scenes_gpu_tree if use is on_gpu_tree else (scenes_leaf8 if use is on_leaf8 else scenes))[name].flat, p)
+        ref, ost = O.render((scenes_gpu_tree if use is on_gpu_tree else (scenes_leaf8 if use is on_leaf8 else (scenes_foreign if use is on_foreign else scenes)))[name].flat, p)
         ok = np.array_equal(img, ref) and (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
         n += 1
         if not ok:
-            print("MISMATCH", name, dict(tile=(x0, y0, x1, y1), spp=spp, seed=seed, flags=flags, max_depth=md, rows=rows, mem_budget=budget_b), flush=True)
+            print("MISMATCH", name, "foreign" if use is on_foreign else ("leaf8" if use is on_leaf8 else ("lbvh" if use is on_gpu_tree else ("alt" if use is alt else "default"))), dict(tile=(x0, y0, x1, y1), spp=spp, seed=seed, flags=flags, max_depth=md, rows=rows, mem_budget=budget_b), flush=True)
             sys.exit(1)
     print(f"fuzz parity: {n} random configurations, all bit-identical to the oracle ({time.time() - t0:.0f} s)")
 
