@@ -86,7 +86,8 @@ typedef struct trt_material {
 } trt_material;
 
 /* One <light> element, XML order (scene.cpp:25-54).  area = Material::area
- * accumulated in readobj (scene.cpp:201-203). */
+ * accumulated in readobj (scene.cpp:201-203).  `radiance` is kept for the caller's convenience only: both the emissive hit
+ * (pathTracing.cpp:11) and the direct term (pathTracing.cpp:65) read materials[mat].radiance, and so does this library. */
 typedef struct trt_light {
     int32_t mat;          /* material id of mtlname */
     float radiance[3];

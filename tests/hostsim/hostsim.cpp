@@ -57,7 +57,7 @@ struct HostScene {
         mats.resize(s->n_materials);
         for (uint32_t i = 0; i < s->n_materials; ++i) mats[i] = makeMaterialDev(s->materials[i]);
         lights.resize(s->n_lights);
-        for (uint32_t i = 0; i < s->n_lights; ++i) lights[i] = makeLightDev(s->lights[i]);
+        for (uint32_t i = 0; i < s->n_lights; ++i) lights[i] = makeLightDev(s->lights[i], s->materials);
         ltris.resize(s->n_light_tris);
         for (uint32_t i = 0; i < s->n_light_tris; ++i) ltris[i] = makeLightTriDev(s->light_tris[i]);
         tex.resize(s->n_textures);

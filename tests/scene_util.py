@@ -166,3 +166,47 @@ def poison_geometry(scene, seed=5, every=40, boxes=False):
                 words[rng.integers(1, f.n_nodes), cols[rng.integers(0, len(cols))]] = val
                 count += 1
     return count
+
+
+HOSTILE_VALUES = [float("nan"), float("inf"), float("-inf"), 1e38, -1e38, 1e-40, 0.0, -0.0, -1.0, 0.5, 1.0, 2.0, 1e6, 1.0000001, 0.99999994]
+
+
+def poison_tables(scene, rng):
+    """One to four hostile values (HOSTILE_VALUES) written IN PLACE into the float fields of the flat scene's tables: a material's Kd / Ks / Tr / Ns / Ni / radiance,
+    a light's radiance / area, a light triangle's vertices / normals / cumulative area, texture coordinates, the camera.  Integer fields (ids, counts, flags) are
+    left alone: trt_create validates those.  Returns what was written, for the assertion message."""
+    import ctypes as C
+
+    import numpy as np
+    from tinyraytracing_amd._abi import Light, LightTri, Material
+    f = scene.flat.contents
+    mats = np.ctypeslib.as_array(C.cast(f.materials, C.POINTER(C.c_float)), (f.n_materials, C.sizeof(Material) // 4))
+    lights = np.ctypeslib.as_array(C.cast(f.lights, C.POINTER(C.c_float)), (f.n_lights, C.sizeof(Light) // 4))
+    ltris = np.ctypeslib.as_array(C.cast(f.light_tris, C.POINTER(C.c_float)), (f.n_light_tris, C.sizeof(LightTri) // 4))
+    tvt = np.ctypeslib.as_array(f.tri_vt, (f.n_tris, 6))
+    what = []
+    for _ in range(int(rng.integers(1, 5))):
+        k = int(rng.integers(0, 5))
+        v = HOSTILE_VALUES[int(rng.integers(0, len(HOSTILE_VALUES)))]
+        if k == 0:
+            m, c = int(rng.integers(0, f.n_materials)), int(rng.integers(0, 14))  # Kd, Ks, Tr, Ns, Ni, radiance
+            mats[m, c] = v
+            what.append(("material", m, c, v))
+        elif k == 1:
+            li, c = int(rng.integers(0, f.n_lights)), int(rng.integers(1, 5))      # radiance, area
+            lights[li, c] = v
+            what.append(("light", li, c, v))
+        elif k == 2:
+            t, c = int(rng.integers(0, f.n_light_tris)), int(rng.integers(0, 19))  # v, vn, cum_area
+            ltris[t, c] = v
+            what.append(("light triangle", t, c, v))
+        elif k == 3:
+            for _ in range(20):
+                tvt[int(rng.integers(0, f.n_tris)), int(rng.integers(0, 6))] = v
+            what.append(("vt", v))
+        else:
+            cam = np.ctypeslib.as_array(C.cast(C.addressof(f.camera), C.POINTER(C.c_float)), (12,))
+            c = int(rng.integers(0, 12))
+            cam[c] = v
+            what.append(("camera", c, v))
+    return what

@@ -912,3 +912,20 @@ def test_non_finite_rays_find_what_the_oracle_finds(name, impl, nk, monkeypatch)
     t1, tri1, uv1 = r.trace_closest(org, dirs)
     r.close()
     assert np.array_equal(tri0, tri1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(uv0.view(np.uint32), uv1.view(np.uint32))
+
+
+def test_hostile_table_values_render_like_the_oracle():
+    """The kernels on 36 scenes with hostile numbers in their tables (scene_util.poison_tables): every launch ends, image bits and ray counts are the oracle's."""
+    for trial in range(36):
+        rng = np.random.default_rng(500 + trial)
+        name = ["back", "veach-mis", "staircase"][trial % 3]
+        s = T.Scene.named(name, 64, 36)
+        what = SU.poison_tables(s, rng)
+        p = T.make_params(64, 36, 4, 2000 + trial, flags=int(rng.choice([0, T.TRT_FLAG_FIXED_NEE, T.TRT_FLAG_RAY_OFFSET, T.TRT_FLAG_SPECULAR_KS, T.TRT_FLAG_OVERLAP])))
+        ref, ost = O.render(s.flat, p)
+        r = T.Renderer(s, 0)
+        img, st = r.render(p)
+        r.close()
+        assert np.array_equal(ref.view(np.uint32), img.view(np.uint32)), (name, what, p.flags)
+        assert st.rays == ost.rays, (name, what, p.flags)
+        s.close()

@@ -457,3 +457,21 @@ def test_non_finite_rays_find_what_the_oracle_finds(name):
         finally:
             H.set_node_kind(old)
         assert np.array_equal(tri0, tri1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(uv0.view(np.uint32), uv1.view(np.uint32)), (name, nk)
+
+
+def test_hostile_table_values_device_code_equals_oracle():
+    """45 scenes with hostile numbers in their material / light / light-triangle / texture-coordinate / camera tables (scene_util.poison_tables: NaN, +-inf, +-1e38,
+    denormal, negative, > 1): same image bits, same ray counts, every flag.  (Round 4 found one field this way: the direct term's radiance is the light MATERIAL's,
+    pathTracing.cpp:65 — the device read trt_light::radiance, the same number in every loaded scene and a different one in a caller's hands.)"""
+    import scene_util as SU
+    for trial in range(45):
+        rng = np.random.default_rng(trial)
+        name = ["back", "veach-mis", "staircase"][trial % 3]
+        s = T.Scene.named(name, 40, 30)
+        what = SU.poison_tables(s, rng)
+        p = T.make_params(40, 30, 4, 1000 + trial, flags=int(rng.choice([0, T.TRT_FLAG_FIXED_NEE, T.TRT_FLAG_RAY_OFFSET, T.TRT_FLAG_SPECULAR_KS])))
+        ref, ost = O.render(s.flat, p)
+        img, rays = H.render(s.flat, p)
+        assert np.array_equal(ref.view(np.uint32), img.view(np.uint32)), (name, what, p.flags)
+        assert rays == [ost.rays_camera, ost.rays_shadow, ost.rays_indirect], (name, what, p.flags)
+        s.close()

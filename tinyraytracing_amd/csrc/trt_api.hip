@@ -493,7 +493,7 @@ int buildSceneImage(const trt_scene* s, SceneImage& im)
     im.mats.resize(s->n_materials);
     for (uint32_t i = 0; i < s->n_materials; ++i) im.mats[i] = makeMaterialDev(s->materials[i]);
     im.lights.resize(s->n_lights);
-    for (uint32_t i = 0; i < s->n_lights; ++i) im.lights[i] = makeLightDev(s->lights[i]);
+    for (uint32_t i = 0; i < s->n_lights; ++i) im.lights[i] = makeLightDev(s->lights[i], s->materials);
     im.ltris.resize(s->n_light_tris);
     for (uint32_t i = 0; i < s->n_light_tris; ++i) im.ltris[i] = makeLightTriDev(s->light_tris[i]);
     // packed CDF for the bisection in lightSample; only when every light's CDF is non-decreasing and NaN-free

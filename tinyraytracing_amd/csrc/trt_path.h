@@ -201,11 +201,13 @@ TRT_HD inline LightTriDev makeLightTriDev(const trt_light_tri& t)
     d.pad = 0.0f;
     return d;
 }
-TRT_HD inline LightDev makeLightDev(const trt_light& l)
+// The radiance of the direct term is the light MATERIAL's (pathTracing.cpp:65 reads scene.materials[light_triangle.mtl_name].radiance), not trt_light::radiance:
+// the loaders write the same three numbers into both (scene.cpp:50-52), a caller of the C-ABI who does not gets what the reference would compute.
+TRT_HD inline LightDev makeLightDev(const trt_light& l, const trt_material* materials)
 {
     LightDev d;
     d.mat = l.mat;
-    for (int k = 0; k < 3; ++k) d.radiance[k] = l.radiance[k];
+    for (int k = 0; k < 3; ++k) d.radiance[k] = materials[l.mat].radiance[k];
     d.area = l.area; d.tri_first = l.tri_first; d.tri_count = l.tri_count; d.pdf = 1.0f / l.area;
     return d;
 }
