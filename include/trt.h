@@ -149,7 +149,7 @@ typedef struct trt_scene {
 #define TRT_FLAG_FIXED_NEE 8u /* opt out of the reference's next-event-estimation quirks: every light's CDF
                               * draw spans that light's own area, light points are uniform on the chosen triangle, and the
                               * shadow test is an occlusion test up to the light sample (any hit in [0.0005, 0.999 * distance)
-                              * blocks; a miss is visible) instead of closest-hit + material comparison.  Off = parity mode. */
+                              * blocks; a miss is visible) instead of closest-hit + material comparison; as everywhere, nothing farther than 114514 is seen (Q7).  Off = parity mode. */
 #define TRT_FLAG_FIXED_PIXELS 16u /* opt out of the pixel-grid quirks (Q1, Q2): pixel (i, j) samples its own cell
                                   * [j/W, (j+1)/W) x [(H-1-i)/H, (H-i)/H) of the image plane uniformly.  Off = parity mode. */
 

@@ -443,7 +443,7 @@ struct PathTracer {
         if (!(cos_s > 0.0f)) return false;  // the reference traces and then discards (pathTracing.cpp:60)
         cnt.rays[1]++;
         if (fixed_nee) {  // visible iff nothing lies in [0.0005, 0.999 |x' - x|)
-            if (shadow.occluded(rayOrigin(vx, wo), wo, 0.999f * length(diff))) return false;
+            if (shadow.occluded(rayOrigin(vx, wo), wo, fminf(0.999f * length(diff), TRT_INF))) return false;  // Q7 holds in this mode too: nothing beyond 114514 is seen (bvh.h:5)
         } else {
             const Hit h = shadow.closest(rayOrigin(vx, wo), wo);
             // Q5: visible iff the CLOSEST hit carries the light's material (pathTracing.cpp:54-58)

@@ -4,6 +4,8 @@
 // the wavefront kernels' order of operations, so their arithmetic can be checked
 // bit-for-bit against the oracle on a machine without a GPU.  It is not a render
 // back end: nothing in the product loads this library.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>

@@ -929,3 +929,39 @@ def test_hostile_table_values_render_like_the_oracle():
         assert np.array_equal(ref.view(np.uint32), img.view(np.uint32)), (name, what, p.flags)
         assert st.rays == ost.rays, (name, what, p.flags)
         s.close()
+
+
+@pytest.mark.parametrize("impl,nk", [("0", "0"), ("3", "0"), ("3", "1")])
+def test_zero_direction_component_on_a_box_plane_takes_the_literal_slab_test(impl, nk, tmp_path, monkeypatch):
+    """The kernels on test_hostsim_parity's vertex-eye scene: the wave-uniform walk switches the rays with a zero direction component to the literal slab test, the
+    per-lane drivers hand them to k_trace_fix (the caller's BVH2, literal test, no culling); hits and image are the oracle's."""
+    from test_hostsim_parity import _vertex_eye_scene
+    monkeypatch.setenv("TRT_TRACE_IMPL", impl)
+    monkeypatch.setenv("TRT_NODE_KIND", nk)
+    s = _vertex_eye_scene(tmp_path)
+    f = s.flat.contents
+    rng = np.random.default_rng(3)
+    rays = [O.camera_ray(f.camera, 24, 5, 1, int(rng.integers(17, 22)), float(np.float32(rng.random())), float(np.float32(rng.random()))) for _ in range(20000)]
+    org, dirs = np.array([r[0] for r in rays], np.float32), np.array([r[1] for r in rays], np.float32)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    assert (tri0[(dirs == 0).any(1)] >= 0).sum() > 50
+    r = T.Renderer(s, 0)
+    t1, tri1, uv1 = r.trace_closest(org, dirs)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+    for flags in (0, T.TRT_FLAG_FIXED_NEE, T.TRT_FLAG_OVERLAP):
+        p = T.make_params(24, 5, 64, 4106463245, max_depth=3, flags=flags)
+        img, st = r.render(p)
+        ref, ost = O.render(s.flat, p)
+        assert_same_image(img, ref, f"vertex eye, impl {impl}, node kind {nk}, flags {flags}")
+        assert st.rays == ost.rays
+    r.close()
+    s.close()
+
+
+def test_random_scenes_render_like_the_oracle():
+    """tools/fuzz_scenes.py --gpu for 40 s: random scenes through the loaders, the builders and the kernels (default handle and both node kinds per lane)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLD), "..", "tools", "fuzz_scenes.py"), "--gpu", "--seconds", "40", "--seed", "9"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "all bit-identical" in r.stdout

@@ -475,3 +475,80 @@ def test_hostile_table_values_device_code_equals_oracle():
         assert np.array_equal(ref.view(np.uint32), img.view(np.uint32)), (name, what, p.flags)
         assert rays == [ost.rays_camera, ost.rays_shadow, ost.rays_indirect], (name, what, p.flags)
         s.close()
+
+
+def _vertex_eye_scene(tmp_path):
+    """One emissive triangle at coordinates of 7e4 (the 0.001 pad of bvh.cpp:31-40 is below one ulp there: the vertex IS a corner of the leaf's box) seen by a
+    camera that sits on one of its vertices: rays whose direction has an exactly zero component start ON a box plane, the slab test multiplies 0 by inf, and
+    glm::min / glm::max (bvh.cpp:238-242) lose the constraint of that axis and of the ones nested inside it — the reference ENTERS the box and finds the triangle."""
+    import scene_util as SU
+    obj = ("v 71246.609375 79342.484375 -881.6929931640625\nv 72923.890625 77794.8359375 476.5187683105469\nv 74036.484375 79794.8046875 -4266.68115234375\n"
+           "vn 0 0 1\nvt 0 0\nusemtl lamp\nf 1/1/1 2/1/1 3/1/1\n")
+    SU.write_scene(tmp_path, "eye", obj, SU.MTL_BASIC, lights=[("lamp", (4, 8, 9.5))], w=24, h=5, fovy=20.0, eye=(74036.484375, 79794.8046875, -4266.68115234375),
+                   lookat=(72698.703125, 79148.5546875, -1440.929931640625))
+    return SU.load(tmp_path, "eye", leaf_num=15)
+
+
+def test_zero_direction_component_on_a_box_plane_takes_the_literal_slab_test(tmp_path):
+    """tools/fuzz_scenes.py, round 4: 155 of 20 000 camera rays of this scene have d.y == 0 exactly and the oracle (the literal slab test) finds the triangle for them;
+    the fast form (fminf / fmaxf: a NaN dropped from either side) missed it.  Rays with such a direction now walk the caller's BVH2 with the literal test
+    (trt_path.h raySpecial / traceClosestBvh2Glm): same hits, same image, both node kinds."""
+    s = _vertex_eye_scene(tmp_path)
+    f = s.flat.contents
+    rng = np.random.default_rng(3)
+    rays = [O.camera_ray(f.camera, 24, 5, 1, int(rng.integers(17, 22)), float(np.float32(rng.random())), float(np.float32(rng.random()))) for _ in range(20000)]
+    org, dirs = np.array([r[0] for r in rays], np.float32), np.array([r[1] for r in rays], np.float32)
+    assert ((dirs == 0).any(1)).sum() > 50
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    assert (tri0[(dirs == 0).any(1)] >= 0).sum() > 50   # the reference does find the triangle through the poisoned test
+    p = T.make_params(24, 5, 16, 4106463245, max_depth=3)
+    ref, ost = O.render(s.flat, p)
+    for nk in (0, 1):
+        old = H.set_node_kind(nk)
+        try:
+            t1, tri1, uv1, _ = H.trace(s.flat, org, dirs)
+            img, rays_n = H.render(s.flat, p)
+        finally:
+            H.set_node_kind(old)
+        assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1), nk
+        assert np.array_equal(ref.view(np.uint32), img.view(np.uint32)), nk
+    s.close()
+
+
+def test_a_light_beyond_the_references_infinity_is_never_seen(tmp_path):
+    """Q7 (bvh.h:5: INF = 114514): a light 128 000 units away is never the closest hit of a shadow ray, so it lights nothing — also when the ray carries a search
+    hint of 1.001 |x' - x| > INF (the 8-wide path took the hint as its bound and found the light; tools/fuzz_scenes.py, round 4), and in TRT_FLAG_FIXED_NEE mode."""
+    import scene_util as SU
+    lines, body, vb = ["vt 0 0", "vn 0 0 1"], "", 1
+    for (z, m, half) in ((0.0, "white", 3.0), (-2.0, "shiny", 4.0)):
+        v, f, vb = SU.quad(-half, half, -half, half, z, vb)
+        lines += v
+        body += f"usemtl {m}\n" + "\n".join(x.format(n=1) for x in f) + "\n"
+    v, f, vb = SU.quad(-20000.0, 20000.0, -20000.0, 20000.0, 128000.0, vb)
+    lines += v
+    body += "usemtl lamp\n" + "\n".join(x.format(n=1) for x in f) + "\n"
+    SU.write_scene(tmp_path, "far", "\n".join(lines) + "\n" + body, SU.MTL_BASIC, lights=[("lamp", (50, 50, 50))], w=24, h=16, eye=(0, 0, 9), lookat=(0, 0, 0))
+    s = SU.load(tmp_path, "far", leaf_num=2)
+    for flags in (0, T.TRT_FLAG_FIXED_NEE):
+        p = T.make_params(24, 16, 8, 11, flags=flags)
+        ref, ost = O.render(s.flat, p)
+        assert ost.rays_shadow > 500 and (flags != 0 or float(ref.max()) == 0.0)   # parity mode: shadow rays are traced, none finds the light (fixed: a miss is visible)
+        for nk in (0, 1):
+            old = H.set_node_kind(nk)
+            try:
+                assert H.compressible(s.flat)
+                img, rays_n = H.render(s.flat, p)
+            finally:
+                H.set_node_kind(old)
+            assert np.array_equal(ref.view(np.uint32), img.view(np.uint32)), (flags, nk)
+    s.close()
+
+
+def test_random_scenes_device_code_equals_oracle():
+    """tools/fuzz_scenes.py for a few seconds: random geometry, materials from every branch of nextRay(), 0-8 lights, random cameras, both builders, leaves of 1-15."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_scenes.py"), "--seconds", "12", "--seed", "5"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "all bit-identical" in r.stdout

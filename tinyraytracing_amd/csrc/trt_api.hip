@@ -628,7 +628,9 @@ int createOnDevice(const SceneImage& im, int device, trt_handle** out)
     }
 
     // traversal spill area: levels beyond the LDS stack, for the largest grid
-    uint32_t spill_levels = h->depth > (uint32_t)TRT_LDS_STACK_MAX ? h->depth - TRT_LDS_STACK_MAX + 1 : 1;
+    // (k_trace_fix / k_tail walk the caller's BVH2 itself for the rays of raySpecial(), trt_path.h: one entry per level of it)
+    const uint32_t stack_levels = std::max(h->depth, h->bvh2_depth + 2u);
+    uint32_t spill_levels = stack_levels > (uint32_t)TRT_LDS_STACK_MAX ? stack_levels - TRT_LDS_STACK_MAX + 1 : 1;
     if (h->node_kind == 1 && h->oct_levels > OCT_LDS_LEVELS) spill_levels = std::max(spill_levels, 2u * (h->oct_levels - OCT_LDS_LEVELS + 1));  // two words per level
     h->spill_words_per_slot = (size_t)spill_levels * SPILL_STRIDE;
     if (int e = h->spill.ensure(h->spill_words_per_slot * 2 * sizeof(uint32_t))) return e;  // one area per concurrent pass

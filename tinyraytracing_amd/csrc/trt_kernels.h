@@ -246,6 +246,7 @@ template <bool SHADOW, bool OCT = false>
 __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 inv, float best_t, int32_t best_tri, uint32_t best_flags, uint32_t idx, uint32_t pid,
                                              f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, bool any)
 {
+    if (raySpecial(inv)) return true;  // a zero direction component: the literal slab test may see a NaN (trt_path.h boxTestGlm) — k_trace_fix walks the BVH2 with it
     const uint32_t tri = best_tri >= 0 ? (uint32_t)best_tri : 0u;
     const f4 ba = sc.leaf_box[2 * (size_t)tri], bb = sc.leaf_box[2 * (size_t)tri + 1];
     if (!SHADOW) {
@@ -302,6 +303,10 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     uint32_t reach = valid ? 1u : 0u;  // bit k: the ray reaches inner node k
     uint32_t n_pend = 0;
+    // A ray with a zero direction component takes the literal slab test (trt_path.h boxTestGlm: a NaN from 0 * inf counts as the reference counts it); the
+    // walk is the reference's own visit set already, so nothing else changes for it.  One vote per ray; the extra test runs only in a wave that holds such a ray.
+    const bool special = valid && raySpecial(inv);
+    const bool any_special = ballotb(special) != 0ull;
     // division + cut + fold of every parked candidate, slot by slot (= in the order they were found)
     auto flush = [&]() {
         for (uint32_t s = 0; ballotb(s < n_pend) != 0ull; ++s) {
@@ -332,8 +337,13 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
         const f4 q0 = np4[0], q1 = np4[1], q2 = np4[2], q3 = np4[3];
         if (COUNT && at) n_inner++;
         float e0 = 0.0f, e1 = 0.0f;
-        const bool h0 = at && boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
-        const bool h1 = at && boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
+        bool h0 = at && boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
+        bool h1 = at && boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
+        if (any_special) {  // wave-uniform
+            float g0, g1;
+            const bool s0 = boxTestGlm(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, g0), s1 = boxTestGlm(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, g1);
+            if (special) { h0 = at && s0; h1 = at && s1; e0 = g0; e1 = g1; }
+        }
         const float f0 = trt_leaf_floor(e0, sc.leaf_alpha), f1 = trt_leaf_floor(e1, sc.leaf_alpha);  // used only where the child is a leaf
         const uint32_t child[2] = {f2u(q3.x), f2u(q3.y)};
         const bool hc[2] = {h0, h1};
@@ -738,7 +748,9 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_fix(SceneDev sc, RayS
             fetchRay<PRIMARY>(sc, src, i, a, b);
             const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
             uint32_t ni = 0, nt = 0;
-            const Hit h = traceClosestPass<LdsStack<TRT_LDS_STACK_MAX, true>, false, NK, true>(sc, o, d, stk, ni, nt, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
+            const Hit h = raySpecial(mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))
+                              ? traceClosestBvh2Glm<LdsStack<TRT_LDS_STACK_MAX, true>, false>(sc, o, d, stk, ni, nt, SHADOW ? b.w : TRT_INF, any)
+                              : traceClosestPass<LdsStack<TRT_LDS_STACK_MAX, true>, false, NK, true>(sc, o, d, stk, ni, nt, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
             storeResult<SHADOW>(sc, o, d, h.t, h.tri, h.flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
         }
     }

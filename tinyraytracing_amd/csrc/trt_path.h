@@ -305,6 +305,31 @@ TRT_HD inline bool boxTest(float lox, float loy, float loz, float hix, float hiy
     return slabResult(inx, iny, inz, outx, outy, outz, entry);
 }
 
+// ---- the slab test LITERALLY, for the rays on which the two forms can differ ----
+// glm::min(x, y) = (y < x) ? y : x and glm::max(x, y) = (x < y) ? y : x (bvh.cpp:238-242) hand a NaN on from their FIRST operand only; fminf / fmaxf (v_min / v_max)
+// drop it from either side.  A NaN arises in the slab test of finite boxes in one way: 0 * inf — a direction component whose reciprocal is infinite (the component
+// is zero or below 2.9e-39) on a ray whose origin lies EXACTLY on a plane of the box.  The reference then loses that axis's constraint AND, by the operand order of
+// bvh.cpp:241-242, those of the axes nested inside the same min / max: it enters boxes the clean test rejects, and finds hits there (a camera on a vertex of a mesh
+// at coordinates where the 0.001 pad is below one ulp: tools/fuzz_scenes.py found it).  Rays with such a direction (raySpecial) are therefore walked by
+// traceClosestBvh2Glm(): the caller's BVH2 as bvh.cpp:146-175 walks it, this test, no culling.  Every other ray cannot produce a NaN from finite operands and keeps
+// the fast forms, which agree with this one on all non-NaN inputs.
+TRT_HD inline float glmMin(float x, float y) { return (y < x) ? y : x; }
+TRT_HD inline float glmMax(float x, float y) { return (x < y) ? y : x; }
+TRT_HD inline bool boxTestGlm(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float& entry)
+{
+    const float inx = (hix - o.x) * inv.x, iny = (hiy - o.y) * inv.y, inz = (hiz - o.z) * inv.z;
+    const float outx = (lox - o.x) * inv.x, outy = (loy - o.y) * inv.y, outz = (loz - o.z) * inv.z;
+    const float tmaxx = glmMax(inx, outx), tmaxy = glmMax(iny, outy), tmaxz = glmMax(inz, outz);
+    const float tminx = glmMin(inx, outx), tminy = glmMin(iny, outy), tminz = glmMin(inz, outz);
+    const float t1 = glmMin(tmaxx, glmMin(tmaxy, tmaxz));
+    const float t0 = glmMax(tminx, glmMax(tminy, tminz));
+    entry = t0;
+    const float r = (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;  // bvh.cpp:244
+    return r > 0.0f;                                                // bvh.cpp:162-166
+}
+// a reciprocal direction with a component that is infinite or NaN
+TRT_HD inline bool raySpecial(f3 inv) { return !(fabsf(inv.x) <= 3.4028235e38f && fabsf(inv.y) <= 3.4028235e38f && fabsf(inv.z) <= 3.4028235e38f); }
+
 // ------------------------------------------------------ one inner-node step ----
 // Children of wide node `cur` that the ray can still improve on: box passed (bvh.cpp:162-166) and entry
 // not STRICTLY beyond the best hit.  Continues with the nearest (returns true, `cur` updated), the others
@@ -479,6 +504,73 @@ TRT_HD inline Hit traceClosestPass(const SceneDev& sc, f3 o, f3 d, Stack& stk, u
     return best;
 }
 
+// traverseBVH on the caller's BVH2 with the literal slab test (boxTestGlm), unculled, for the rays of raySpecial(): every box the ray passes is entered (bvh.cpp:162-166),
+// every triangle of a leaf so reached is tested and held to the leaf-box rule with the entry distance of THIS test (the oracle's leafScan), leaves are merged by the
+// order-independent form of bvh.cpp:168-172.  `any`: the occlusion test of TRT_FLAG_FIXED_NEE (a hit nearer than t_init ends the search).  Stack: <= BVH2 depth entries.
+template <class Stack, bool COUNT>
+TRT_HD inline Hit traceClosestBvh2Glm(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init, bool any)
+{
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    Hit best;
+    best.t = any ? t_init : TRT_INF; best.tri = -1; best.u = 0.f; best.v = 0.f; best.flags = 0u;
+    float best_det = 1.0f;
+    int sp = 0;
+    uint32_t cur = 0;  // nodes[0] is always an inner node
+    for (;;) {
+        if (cur & TRT_LEAF_BIT) {
+            const uint32_t first = TRT_LEAF_FIRST(cur), count = TRT_LEAF_COUNT(cur);
+            float lt = TRT_INF, lun = 0.f, lvn = 0.f, ldet = 1.0f;
+            int32_t li = -1;
+            uint32_t lflags = 0u;
+            if (count) {
+                const f4 ba = sc.leaf_box[2 * (size_t)first], bb = sc.leaf_box[2 * (size_t)first + 1];  // the box this leaf was entered through
+                float e;
+                (void)boxTestGlm(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
+                const float floor_t = trt_leaf_floor(e, sc.leaf_alpha);
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t i = first + k;
+                    const TriIsect T = sc.tri_isect[i];
+                    if (COUNT) n_tri++;
+                    float t, un, vn, det;
+                    if (triTest(T, o, d, t, un, vn, det) && !(t < floor_t)) {
+                        const uint32_t fl = f2u(T.c.z);
+                        if ((t == lt && (fl & 1u)) || t < lt) { lt = t; li = (int32_t)i; lun = un; lvn = vn; ldet = det; lflags = fl; }
+                    }
+                }
+            }
+            if (li >= 0) {
+                bool take = lt < best.t;
+                if (lt == best.t && best.tri >= 0) {
+                    const bool lem = (lflags & 1u) != 0, bem = (best.flags & 1u) != 0;
+                    take = lem ? (!bem || li < best.tri) : (!bem && li > best.tri);
+                }
+                if (take) { best.t = lt; best.tri = li; best.u = lun; best.v = lvn; best_det = ldet; best.flags = lflags; }
+            }
+            if (sp == 0 || (any && best.tri >= 0)) break;
+            cur = stk.pop(--sp);
+            continue;
+        }
+        if (COUNT) n_inner++;
+        const trt_bvh_node& nd = sc.nodes[cur];
+        float e0, e1;
+        const bool h0 = boxTestGlm(nd.lo0[0], nd.lo0[1], nd.lo0[2], nd.hi0[0], nd.hi0[1], nd.hi0[2], o, inv, e0);
+        const bool h1 = boxTestGlm(nd.lo1[0], nd.lo1[1], nd.lo1[2], nd.hi1[0], nd.hi1[1], nd.hi1[2], o, inv, e1);
+        const uint32_t c0 = nd.child0, c1 = nd.child1;
+        if (h0 && h1) { stk.push(sp++, c1); cur = c0; }
+        else if (h0) cur = c0;
+        else if (h1) cur = c1;
+        else {
+            if (sp == 0) break;
+            cur = stk.pop(--sp);
+        }
+    }
+    if (best.tri >= 0) {
+        best.u = best.u / best_det;
+        best.v = best.v / best_det;
+    }
+    return best;
+}
+
 // does the hit (t, tri) lie in front of the box of tri's leaf by more than the tolerance?  (leafFloor(): such a hit does not count)
 TRT_HD inline bool hitInFrontOfItsLeaf(const SceneDev& sc, float t, int32_t tri, f3 o, f3 inv)
 {
@@ -488,6 +580,7 @@ template <class Stack, bool COUNT, int NK = 0>
 TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false,
                                bool redo = false)
 {
+    if (raySpecial(mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) return traceClosestBvh2Glm<Stack, COUNT>(sc, o, d, stk, n_inner, n_tri, t_init, any);
     const Hit h = traceClosestPass<Stack, COUNT, NK, false>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo);
     if (!hitInFrontOfItsLeaf(sc, h.t, h.tri, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) return h;
     return traceClosestPass<Stack, COUNT, NK, true>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo);
@@ -699,7 +792,7 @@ TRT_HD inline bool lightSample(const SceneDev& sc, const Vertex& vx, const Mater
     wo = diff * diff_rlen;
     const float cos_s = dot(wo, vx.pn);
     if (!(cos_s > 0.0f)) return false;  // pathTracing.cpp:60: such a sample never contributes
-    t_max = (fixed ? 0.999f : 1.001f) * diff_len;
+    t_max = fminf((fixed ? 0.999f : 1.001f) * diff_len, TRT_INF);  // Q7: nothing beyond 114514 is ever a hit (bvh.h:5, bvh.cpp:219), hint and occlusion range included
     const float pdf_light = L.pdf;  // 1 / area, makeLightDev
     const float cos_theta_p = fabsf(dot(wo, light_n));
     const float cos_theta = fabsf(cos_s / length(vx.pn));
