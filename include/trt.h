@@ -209,8 +209,10 @@ typedef struct trt_stats {
     uint32_t inner_node_bytes;  /* bytes one inner-node visit fetches: 64 (the caller's BVH2 node: two boxes + refs, tiny scenes),
                                  * 128 (its exact 4-wide collapse: four boxes + refs) or 80 (its 8-wide collapse with quantised boxes) */
     uint32_t redo_rays;         /* rays whose traversal result failed the check made when it is stored (a hit in front of the box of its
-                                 * own leaf, or — 8-wide nodes — on a leaf whose exact box the ray misses) and that were traced again in
-                                 * the exact form: a handful per 10^7 on padded trees; a large number says the slow path is carrying the render */
+                                 * own leaf, or — 8-wide nodes — on a leaf whose exact box the ray misses), and rays with a direction component
+                                 * of exactly zero (for them the reference's slab test can meet 0 * inf; they are traced with its literal form where
+                                 * their origin may lie on a box plane), traced again in the exact form: a handful per 10^7, respectively one or two
+                                 * per 10^5, on padded trees; a large number says the slow path is carrying the render */
     uint64_t lane_census[4];    /* TRT_FLAG_COUNT, persistent traversal kernels: summed over every wave iteration, the lanes waiting for a node
                                  * step [0], for a triangle step [1], holding a finished ray that waits for the refill batch [2]; [3] = the
                                  * iterations (x 64 = lane slots; what is left held no ray) — where the idle SIMD lanes are */

@@ -43,6 +43,7 @@ struct HostScene {
     OctTree oct;
     std::vector<f4> leaf_boxes;
     std::vector<LightBox> light_boxes;
+    std::vector<uint32_t> plane_bits;
     int nk = 0;  // node kind the traversal walks: 0 exact 4-wide nodes, 1 compressed 8-wide nodes (TRT_NODE_KIND)
     SceneDev sc{};
     explicit HostScene(const trt_scene* s)
@@ -82,6 +83,8 @@ struct HostScene {
         light_boxes = lightBoxesOf(leaf_boxes, s->tri_mat, s->n_tris, s->lights, s->n_lights);
         sc.leaf_box = leaf_boxes.data();
         sc.leaf_alpha = sceneLeafAlpha(s->nodes, s->n_nodes);
+        sc.plane_shift = 32u - wide_detail::planeFilterBuild(s->nodes, s->n_nodes, plane_bits);
+        sc.plane_bits = plane_bits.data();
         sc.cull_alpha = wide_detail::boxesNested(s->nodes, s->n_nodes) ? sc.leaf_alpha : std::numeric_limits<float>::infinity();  // as trt_create
         nk = (oct.ok && g_node_kind != 0) ? 1 : 0;
         sc.tri_isect = isect.data();

@@ -965,3 +965,20 @@ def test_random_scenes_render_like_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLD), "..", "tools", "fuzz_scenes.py"), "--gpu", "--seconds", "40", "--seed", "9"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "all bit-identical" in r.stdout
+
+
+def test_a_queue_full_of_axis_aligned_rays(renderer_factory):
+    """8 M rays of which half have a zero direction component, on the Cornell box (wave-uniform walk): every wave parks more such rays than its list holds and
+    goes over its share a second time with the literal slab test; 300 k of them on staircase (per-lane kernels: all of those go through k_trace_fix).  Same hits."""
+    s = get_scene("back", 64, 64)
+    org, dirs = raygen.adversarial_rays(s, 8000000)
+    t0, tri0, uv0 = O.trace(s.flat, org, dirs)
+    t1, tri1, uv1, st = renderer_factory(s).trace_closest(org, dirs, want_stats=True)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+    assert st.redo_rays > 3000000
+    s2 = get_scene("staircase", 64, 36)
+    org, dirs = raygen.adversarial_rays(s2, 300000)
+    t0, tri0, uv0 = O.trace(s2.flat, org, dirs)
+    t1, tri1, uv1, st = renderer_factory(s2).trace_closest(org, dirs, want_stats=True)
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1) and np.array_equal(uv0, uv1)
+    assert st.redo_rays > 100000

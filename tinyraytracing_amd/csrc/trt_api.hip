@@ -395,6 +395,8 @@ struct SceneImage {
     std::vector<uint8_t> tex_bytes;
     float leaf_alpha = 0.0f;
     float cull_alpha = 0.0f;  // leaf_alpha, or +inf for a tree whose boxes do not nest (SceneDev::cull_alpha)
+    std::vector<uint32_t> plane_bits;  // Bloom filter over the box planes (trt_path.h planeMaybe)
+    uint32_t plane_lg = 0;
     bool nested = true;
 };
 
@@ -476,6 +478,7 @@ int buildSceneImage(const trt_scene* s, SceneImage& im)
     // Culling by distance rests on nested boxes; a foreign tree that breaks the premise is walked without it (every box the ray passes is entered, bvh.cpp:162-166)
     im.nested = wide_detail::boxesNested(s->nodes, s->n_nodes, im.threads);
     im.cull_alpha = im.nested ? im.leaf_alpha : std::numeric_limits<float>::infinity();
+    im.plane_lg = wide_detail::planeFilterBuild(s->nodes, s->n_nodes, im.plane_bits, im.threads);
     if (im.dbg && !im.nested) std::fprintf(stderr, "[trt] the boxes of this tree do not nest: traversal without distance culling\n");
     lap("leaf boxes, light boxes");
     // The 8-wide compressed nodes (trt_oct.h) for the persistent traversal kernels, when the tree qualifies (nested, finite; larger
@@ -559,6 +562,8 @@ int createOnDevice(const SceneImage& im, int device, trt_handle** out)
     h->light_boxes = im.light_boxes;
 
     if (int e = upload(h.get(), im.isect.data(), im.isect.size(), &h->sc.tri_isect)) return e;
+    if (int e = upload(h.get(), im.plane_bits.data(), im.plane_bits.size(), &h->sc.plane_bits)) return e;
+    h->sc.plane_shift = 32u - im.plane_lg;
     if (int e = upload(h.get(), im.shade.data(), im.shade.size(), &h->sc.tri_shade)) return e;
     if (int e = upload(h.get(), s->nodes, (size_t)s->n_nodes, &h->sc.nodes)) return e;
     h->sc.n_wnodes = (uint32_t)im.wide.nodes.size();

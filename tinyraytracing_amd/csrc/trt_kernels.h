@@ -246,14 +246,16 @@ template <bool SHADOW, bool OCT = false>
 __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 inv, float best_t, int32_t best_tri, uint32_t best_flags, uint32_t idx, uint32_t pid,
                                              f4* __restrict__ hit, const f4* __restrict__ sw, uint32_t light_mat, f4* __restrict__ Lacc, bool any)
 {
-    if (raySpecial(inv)) return true;  // a zero direction component: the literal slab test may see a NaN (trt_path.h boxTestGlm) — k_trace_fix walks the BVH2 with it
+    // a zero direction component: the literal slab test may see a NaN (trt_path.h boxTestGlm) — k_trace_fix walks the BVH2 with it.  Folded into the conditions
+    // below, behind the loads: a branch in front of them cost 3 % of the traversal kernels' time.
+    const bool special = raySpecial(inv);
     const uint32_t tri = best_tri >= 0 ? (uint32_t)best_tri : 0u;
     const f4 ba = sc.leaf_box[2 * (size_t)tri], bb = sc.leaf_box[2 * (size_t)tri + 1];
     if (!SHADOW) {
         const TriIsect T = sc.tri_isect[tri];
         float e;
         const bool pass = boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
-        if (best_tri >= 0 && ((OCT && !pass) || best_t < trt_leaf_floor(e, sc.leaf_alpha))) return true;
+        if (special || (best_tri >= 0 && ((OCT && !pass) || best_t < trt_leaf_floor(e, sc.leaf_alpha)))) return true;
         float u = 0.f, v = 0.f;
         if (best_tri >= 0) {
             float t, un, vn, det;
@@ -266,7 +268,7 @@ __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 
         if (vis) { w = sw[idx]; L = Lacc[pid]; }
         float e;
         const bool pass = boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
-        if (best_tri >= 0 && ((OCT && !pass) || best_t < trt_leaf_floor(e, sc.leaf_alpha))) return true;
+        if (special || (best_tri >= 0 && ((OCT && !pass) || best_t < trt_leaf_floor(e, sc.leaf_alpha)))) return true;
         if (vis) {
             L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
             Lacc[pid] = L;
@@ -295,18 +297,15 @@ __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 
 constexpr int TRT_PEND_SLOTS = 4;
 // The walk itself for the rays the active lanes of a wave hold (`valid`: this lane has one).  best_t comes in as the
 // bound of the search (TRT_INF, or an occlusion range) and goes out with best_tri / best_flags as the closest hit.
-template <bool COUNT, int STRIDE = TRT_TRACE_BLOCK>
-__device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool valid, f4* __restrict__ my_pend, float& best_t, int32_t& best_tri,
-                                            uint32_t& best_flags, uint32_t& n_inner, uint32_t& n_tri)
+// GLM: this wave holds a ray with a zero direction component (`special` lanes): those lanes take the literal slab test (trt_path.h boxTestGlm: a NaN from 0 * inf
+// counts as the reference counts it); the walk is the reference's own visit set already, so nothing else changes for them.
+template <bool COUNT, int STRIDE, bool GLM>
+__device__ __forceinline__ void uniformWalkImpl(const SceneDev& sc, f3 o, f3 d, f3 inv, bool valid, bool special, f4* __restrict__ my_pend, float& best_t, int32_t& best_tri,
+                                                uint32_t& best_flags, uint32_t& n_inner, uint32_t& n_tri)
 {
     const uint32_t n_nodes = sc.n_nodes;
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     uint32_t reach = valid ? 1u : 0u;  // bit k: the ray reaches inner node k
     uint32_t n_pend = 0;
-    // A ray with a zero direction component takes the literal slab test (trt_path.h boxTestGlm: a NaN from 0 * inf counts as the reference counts it); the
-    // walk is the reference's own visit set already, so nothing else changes for it.  One vote per ray; the extra test runs only in a wave that holds such a ray.
-    const bool special = valid && raySpecial(inv);
-    const bool any_special = ballotb(special) != 0ull;
     // division + cut + fold of every parked candidate, slot by slot (= in the order they were found)
     auto flush = [&]() {
         for (uint32_t s = 0; ballotb(s < n_pend) != 0ull; ++s) {
@@ -339,7 +338,7 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
         float e0 = 0.0f, e1 = 0.0f;
         bool h0 = at && boxTest(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, e0);
         bool h1 = at && boxTest(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, e1);
-        if (any_special) {  // wave-uniform
+        if (GLM) {
             float g0, g1;
             const bool s0 = boxTestGlm(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, g0), s1 = boxTestGlm(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, g1);
             if (special) { h0 = at && s0; h1 = at && s1; e0 = g0; e1 = g1; }
@@ -375,6 +374,17 @@ __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool
     }
     flush();
 }
+// One vote per ray; the second instantiation runs only in a wave that holds a ray with a zero direction component (inside the node loop even a wave-uniform
+// branch cost the headline's traversal 4 %).
+template <bool COUNT, int STRIDE = TRT_TRACE_BLOCK>
+__device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool valid, f4* __restrict__ my_pend, float& best_t, int32_t& best_tri,
+                                            uint32_t& best_flags, uint32_t& n_inner, uint32_t& n_tri)
+{
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool special = valid && raySpecial(inv);
+    if (ballotb(special) != 0ull) uniformWalkImpl<COUNT, STRIDE, true>(sc, o, d, inv, valid, special, my_pend, best_t, best_tri, best_flags, n_inner, n_tri);
+    else uniformWalkImpl<COUNT, STRIDE, false>(sc, o, d, inv, valid, false, my_pend, best_t, best_tri, best_flags, n_inner, n_tri);
+}
 
 template <bool SHADOW, bool COUNT, bool PRIMARY>
 __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
@@ -386,6 +396,33 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
     const uint32_t lb = xcdSwizzle(blockIdx.x, gridDim.x);
     const uint32_t stride = gridDim.x * TRT_TRACE_BLOCK;
     f4* my_pend = pend + threadIdx.x;  // slot s of this lane: my_pend[s * TRT_TRACE_BLOCK]
+    // Rays with a zero direction component (raySpecial, trt_path.h: the literal slab test may see 0 * inf where the clean one does not) are not stored by the
+    // walk below but parked — queue index only, per wave, in LDS — and walked again with the literal test by their own wave when it runs out of rays (up to 128
+    // of them; a wave that meets more goes over its share a second time).  About one ray in 10^5 on the Cornell box.  Nothing of this sits inside the walk or
+    // calls it from inside the loop (a wave-uniform branch in the walk cost 4 %, a call of the second walk from the loop 50 %: the compiler's doing), and no other
+    // wave waits for it (handed to the last block of the launch, that block walked alone, latency-bound: +60 %).  What remains is +4 % on k_trace_closest of the
+    // Cornell box for three compares, a vote and a predicated store (profiles/r04_hardening.txt).
+    __shared__ uint32_t s_parked[2 * TRT_TRACE_BLOCK];
+    uint32_t* my_parked = s_parked + (threadIdx.x >> 6) * 128u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_parked = 0;  // wave-uniform
+    auto rewalk = [&]() {
+        for (uint32_t base = 0; base < n_parked; base += 64u) {
+            const bool valid = base + lane < n_parked;
+            const uint32_t i = my_parked[valid ? base + lane : 0u];
+            f4 a, b;
+            fetchRay<PRIMARY>(sc, src, i, a, b);
+            const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+            float best_t = any ? b.w : TRT_INF;
+            int32_t best_tri = -1;
+            uint32_t best_flags = 0u;
+            uint32_t ni = 0, nt = 0;
+            uniformWalkImpl<false, TRT_TRACE_BLOCK, true>(sc, o, d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), valid, valid, my_pend, best_t, best_tri, best_flags, ni, nt);
+            if (valid) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
+        }
+        if (lane == 0 && n_parked) atomicAdd(&stats->redo_rays, n_parked);
+        n_parked = 0;
+    };
     for (uint32_t base = lb * TRT_TRACE_BLOCK; base < n; base += stride) {
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < n;
@@ -393,11 +430,41 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
         f4 a, b;
         fetchRay<PRIMARY>(sc, src, ii, a, b);
         const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         float best_t = any ? b.w : TRT_INF;
         int32_t best_tri = -1;
         uint32_t best_flags = 0u;
-        uniformWalk<COUNT>(sc, o, d, valid, my_pend, best_t, best_tri, best_flags, n_inner, n_tri);
-        if (valid) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
+        uniformWalkImpl<COUNT, TRT_TRACE_BLOCK, false>(sc, o, d, inv, valid, false, my_pend, best_t, best_tri, best_flags, n_inner, n_tri);
+        const bool special = valid && raySpecial(inv);
+        if (valid && !special) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
+        const unsigned long long m_sp = ballotb(special);
+        if (m_sp != 0ull) {  // (wave-uniform, rare)
+            const uint32_t at = n_parked + (uint32_t)__popcll(m_sp & ((1ull << lane) - 1ull));
+            if (special && at < 128u) my_parked[at] = i;
+            n_parked += (uint32_t)__popcll(m_sp);  // beyond 128: counted, not kept (see below)
+        }
+    }
+    if (n_parked != 0u && n_parked <= 128u) rewalk();
+    else if (n_parked > 128u) {
+        // more than the list holds — a scene that aims whole rows of rays along an axis: this wave goes over its share of the queue once more and walks the
+        // batches that hold such rays with the literal test (their results were not stored above)
+        for (uint32_t base = lb * TRT_TRACE_BLOCK; base < n; base += stride) {
+            const uint32_t i = base + threadIdx.x;
+            const bool valid = i < n;
+            f4 a, b;
+            fetchRay<PRIMARY>(sc, src, valid ? i : n - 1, a, b);
+            const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+            const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            const bool special = valid && raySpecial(inv);
+            if (ballotb(special) == 0ull) continue;
+            float best_t = any ? b.w : TRT_INF;
+            int32_t best_tri = -1;
+            uint32_t best_flags = 0u;
+            uint32_t ni = 0, nt = 0;
+            uniformWalkImpl<false, TRT_TRACE_BLOCK, true>(sc, o, d, inv, special, special, my_pend, best_t, best_tri, best_flags, ni, nt);
+            if (special) storeResult<SHADOW>(sc, o, d, best_t, best_tri, best_flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);
+        }
+        if (lane == 0) atomicAdd(&stats->redo_rays, n_parked);
     }
     if (COUNT) {
         const unsigned long long si = waveSum(n_inner), st = waveSum(n_tri);
@@ -407,6 +474,7 @@ __device__ __forceinline__ void traceQueueUniform(const SceneDev& sc, const RayS
         }
     }
 }
+
 
 template <bool SHADOW, bool COUNT, int DEPTH, bool SPILL, int IMPL, bool PRIMARY, int NK>
 __device__ __forceinline__ void traceQueuePersistent(const SceneDev& sc, const RaySource& src, uint32_t n, f4* __restrict__ hit,
@@ -748,7 +816,8 @@ __global__ __launch_bounds__(TRT_TRACE_BLOCK) void k_trace_fix(SceneDev sc, RayS
             fetchRay<PRIMARY>(sc, src, i, a, b);
             const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
             uint32_t ni = 0, nt = 0;
-            const Hit h = raySpecial(mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))
+            const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            const Hit h = (raySpecial(inv) && rayOnABoxPlane(sc, o, inv))
                               ? traceClosestBvh2Glm<LdsStack<TRT_LDS_STACK_MAX, true>, false>(sc, o, d, stk, ni, nt, SHADOW ? b.w : TRT_INF, any)
                               : traceClosestPass<LdsStack<TRT_LDS_STACK_MAX, true>, false, NK, true>(sc, o, d, stk, ni, nt, SHADOW ? b.w : TRT_INF, any, SHADOW && !any);
             storeResult<SHADOW>(sc, o, d, h.t, h.tri, h.flags, i, SHADOW ? f2u(b.z) : 0u, hit, sw, light_mat, Lacc, any);

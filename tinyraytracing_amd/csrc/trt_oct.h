@@ -271,7 +271,14 @@ template <class StackO, class StackW, bool COUNT>
 TRT_HD inline Hit traceClosestOct(const SceneDev& sc, f3 o, f3 d, StackO& stk, StackW& stkw, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF,
                                   bool any = false, bool redo = false, const LightBox* lbox = nullptr)
 {
-    if (raySpecial(mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) return traceClosestBvh2Glm<StackW, COUNT>(sc, o, d, stkw, n_inner, n_tri, t_init, any);  // trt_path.h
+    {   // a zero direction component: not on the quantised nodes (their slab arithmetic meets 0 * inf at planes of its own) — the exact nodes, or, where the origin
+        // may lie on a box plane, the literal walk (trt_path.h); what k_trace_fix does with such a ray
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        if (raySpecial(inv)) {
+            if (rayOnABoxPlane(sc, o, inv)) return traceClosestBvh2Glm<StackW, COUNT>(sc, o, d, stkw, n_inner, n_tri, t_init, any);
+            return traceClosestPass<StackW, COUNT, 0, true>(sc, o, d, stkw, n_inner, n_tri, t_init, any, redo);
+        }
+    }
     const Hit h = traceOctPass<StackO, COUNT>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo, lbox);
     if (octResultCounts(sc, h.t, h.tri, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) return h;
     return traceClosestPass<StackW, COUNT, 0, true>(sc, o, d, stkw, n_inner, n_tri, t_init, any, redo);

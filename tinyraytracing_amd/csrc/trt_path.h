@@ -146,6 +146,8 @@ struct SceneDev {
     uint32_t leaf_loop;   // oct driver: triangles a lane tests per leaf step (trt_kernels.h; 2 for trees with leaves of <= 3, more where the caller's leaves are larger)
     float light0_area;  // Q3: every light's CDF draw spans lights[0].area (pathTracing.cpp:38)
     float leaf_alpha;   // absolute part of the leaf-box rule's tolerance (trt_leaf_floor, trt_prims.h): sceneLeafAlpha()
+    const uint32_t* plane_bits;  // one-hash Bloom filter over every box plane of the caller's tree, keyed (axis, coordinate): planeMaybe() — null = "maybe" for every query
+    uint32_t plane_shift;        // 32 - log2(bits of the filter)
     float cull_alpha;   // what trt_cull_bound() gets on the 4-wide nodes: leaf_alpha where the boxes of the tree nest, +inf (never cull by distance) where they do not (trt_wide.h boxesNested)
     trt_camera cam;
 };
@@ -329,6 +331,21 @@ TRT_HD inline bool boxTestGlm(float lox, float loy, float loz, float hix, float 
 }
 // a reciprocal direction with a component that is infinite or NaN
 TRT_HD inline bool raySpecial(f3 inv) { return !(fabsf(inv.x) <= 3.4028235e38f && fabsf(inv.y) <= 3.4028235e38f && fabsf(inv.z) <= 3.4028235e38f); }
+// Even such a ray meets a NaN only if its origin lies EXACTLY on a plane of some box, on an axis whose reciprocal is infinite: (plane - o) * inf is NaN for plane == o
+// alone.  A one-hash Bloom filter over all box planes of the tree (built by trt_create: planeFilterBuild, trt_wide.h) answers "certainly not" for almost every origin;
+// only the rays it cannot clear pay for the unculled walk (which on a million-triangle soup visits tens of thousands of nodes).  No false "no": -0 and +0 share a key.
+TRT_HD inline uint32_t planeKey(int axis, float x) { return (f2u(x + 0.0f) * 2654435761u) ^ ((uint32_t)(axis + 1) * 0x9E3779B9u); }
+TRT_HD inline bool planeMaybe(const SceneDev& sc, int axis, float x)
+{
+    if (!sc.plane_bits) return true;
+    const uint32_t h = (planeKey(axis, x) * 2246822519u) >> sc.plane_shift;
+    return (sc.plane_bits[h >> 5] >> (h & 31u)) & 1u;
+}
+TRT_HD inline bool rayOnABoxPlane(const SceneDev& sc, f3 o, f3 inv)
+{
+    return (!(fabsf(inv.x) <= 3.4028235e38f) && planeMaybe(sc, 0, o.x)) || (!(fabsf(inv.y) <= 3.4028235e38f) && planeMaybe(sc, 1, o.y)) ||
+           (!(fabsf(inv.z) <= 3.4028235e38f) && planeMaybe(sc, 2, o.z));
+}
 
 // ------------------------------------------------------ one inner-node step ----
 // Children of wide node `cur` that the ray can still improve on: box passed (bvh.cpp:162-166) and entry
@@ -580,7 +597,10 @@ template <class Stack, bool COUNT, int NK = 0>
 TRT_HD inline Hit traceClosest(const SceneDev& sc, f3 o, f3 d, Stack& stk, uint32_t& n_inner, uint32_t& n_tri, float t_init = TRT_INF, bool any = false,
                                bool redo = false)
 {
-    if (raySpecial(mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) return traceClosestBvh2Glm<Stack, COUNT>(sc, o, d, stk, n_inner, n_tri, t_init, any);
+    {
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        if (raySpecial(inv) && rayOnABoxPlane(sc, o, inv)) return traceClosestBvh2Glm<Stack, COUNT>(sc, o, d, stk, n_inner, n_tri, t_init, any);
+    }
     const Hit h = traceClosestPass<Stack, COUNT, NK, false>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo);
     if (!hitInFrontOfItsLeaf(sc, h.t, h.tri, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) return h;
     return traceClosestPass<Stack, COUNT, NK, true>(sc, o, d, stk, n_inner, n_tri, t_init, any, redo);

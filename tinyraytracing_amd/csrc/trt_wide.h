@@ -289,6 +289,27 @@ inline bool boxesNested(const trt_bvh_node* nodes, uint32_t n_nodes, unsigned th
     return ok.load();
 }
 
+// The filter of planeMaybe() (trt_path.h): one bit per (axis, coordinate) of every stored box plane, 4-8 bits of table per entry (a false "maybe" costs one slow
+// walk of a ray that is rare to begin with; a false "no" cannot happen).  Returns log2 of the number of bits.
+inline uint32_t planeFilterBuild(const trt_bvh_node* nodes, uint32_t n_nodes, std::vector<uint32_t>& bits, unsigned threads = 1)
+{
+    uint32_t lg = 10;
+    while (lg < 32 && (1ull << lg) < 48ull * n_nodes) ++lg;  // 12 entries per node, >= 4 bits each
+    bits.assign((size_t)((1ull << lg) / 32), 0u);
+    const uint32_t shift = 32u - lg;
+    std::atomic<uint32_t>* words = reinterpret_cast<std::atomic<uint32_t>*>(bits.data());
+    par::forRange(n_nodes, threads ? threads : 1, 65536, [&](size_t n0, size_t n1) {
+        for (size_t n = n0; n < n1; ++n) {
+            const trt_bvh_node& nd = nodes[n];
+            for (int a = 0; a < 3; ++a)
+                for (float x : {nd.lo0[a], nd.hi0[a], nd.lo1[a], nd.hi1[a]}) {
+                    const uint32_t h = (planeKey(a, x) * 2246822519u) >> shift;
+                    words[h >> 5].fetch_or(1u << (h & 31u), std::memory_order_relaxed);
+                }
+        }
+    });
+    return lg;
+}
 }  // namespace wide_detail
 
 // `nodes` must have passed validateBvh (every inner node reachable exactly once, indices in range).
