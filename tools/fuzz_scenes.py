@@ -168,7 +168,7 @@ def main():
         try:
             desc, w, h = write_random_scene(d, rng)
             leaf = int(rng.choice([1, 2, 2, 3, 4, 8, 8, 15]))
-            builder = str(rng.choice(["sweep", "binned", "auto"]))
+            builder = str(rng.choice(["sweep", "binned", "auto"] + (["lbvh", "lbvh"] if a.gpu else [])))  # with --gpu: the GPU builder's trees too (leaves of <= 2)
             try:
                 s = T.Scene.load(os.path.join(d, "s.xml"), os.path.join(d, "s.obj"), os.path.join(d, "s.mtl"), d, 0, 0)
                 s.build_bvh(leaf, builder)
@@ -184,6 +184,12 @@ def main():
                 if rng.random() < 0.25: flags |= T.TRT_FLAG_SPECULAR_KS
                 if rng.random() < 0.3: flags |= T.TRT_FLAG_OVERLAP
                 p = T.make_params(w, h, int(rng.choice([1, 2, 5, 16])), int(rng.integers(0, 2 ** 32)), max_depth=int(rng.choice([0, 0, 0, 1, 3])), flags=flags)
+                if rng.random() < 0.3:  # a tile and a row interleave of it
+                    x0 = int(rng.integers(0, w - 1)); y0 = int(rng.integers(0, h - 1))
+                    rows = (int(rng.choice([1, 2])), int(rng.choice([2, 3])), 0) if rng.random() < 0.5 else None
+                    p = T.make_params(w, h, p.spp, p.seed, tile=(x0, y0, int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1))), rows=rows, max_depth=p.max_depth, flags=flags)
+                    if not T.rows_selected(p):
+                        continue
                 ref, ost = O.render(s.flat, p)
                 want = [ost.rays_camera, ost.rays_shadow, ost.rays_indirect]
                 results = []
@@ -205,6 +211,21 @@ def main():
                         img, st = r.render(p)
                         r.close()
                         results.append((f"kernels {env}", img, [st.rays_camera, st.rays_shadow, st.rays_indirect]))
+                if a.gpu and rng.random() < 0.3 and p.spp >= 2:  # the progressive entry point: the same samples in two or three calls, resumed from the sums
+                    r = T.Renderer(s, 0)
+                    cuts = sorted(set([0, p.spp] + [int(x) for x in rng.integers(1, p.spp, 2)]))
+                    acc, img = None, None
+                    for b, e in zip(cuts[:-1], cuts[1:]):
+                        img, acc, _ = r.render_samples(p, b, e, acc)
+                    r.close()
+                    results.append((f"trt_render_samples in {len(cuts) - 1} calls", img, want))
+                if a.gpu and rng.random() < 0.25 and (p.x0, p.y0, p.x1, p.y1) == (0, 0, w, h) and p.row_mod <= 1:  # a device group of 2-3 handles on the one GPU, interleaved stripes
+                    g = T.GroupRenderer(s, [0] * int(rng.choice([2, 3])))
+                    pg = T.make_params(w, h, p.spp, p.seed, max_depth=p.max_depth, flags=flags)
+                    pg.row_block = int(rng.choice([1, 2, 8]))
+                    img, stg, _ = g.render(pg)
+                    g.close()
+                    results.append((f"device group of {len(g.devices)}, row_block {pg.row_block}", img, [stg.rays_camera, stg.rays_shadow, stg.rays_indirect]))
                 for what, img, rays in results:
                     n_render += 1
                     if not (np.array_equal(ref.view(np.uint32), img.view(np.uint32)) and rays == want):
