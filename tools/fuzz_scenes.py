@@ -28,8 +28,8 @@ def fmt(x):
     return repr(float(np.float32(x)))
 
 
-def write_random_scene(d, rng):
-    """returns (description, width, height)"""
+def write_random_scene(d, rng, big=False):
+    """returns (description, width, height); big: now and then a few thousand to tens of thousands of triangles (deep trees, spilled stacks, many waves)"""
     n_mat = int(rng.integers(1, 13))
     mats = []
     tex_id = 0
@@ -64,7 +64,7 @@ def write_random_scene(d, rng):
             f.write(f"newmtl {m['name']}\nKd {' '.join(fmt(x) for x in m['Kd'])}\nKs {' '.join(fmt(x) for x in m['Ks'])}\nTr {' '.join(fmt(x) for x in m['Tr'])}\n"
                     f"Ns {fmt(m['Ns'])}\nNi {fmt(m['Ni'])}\n" + (f"map_Kd {m['tex']}\n" if m["tex"] else ""))
     # geometry
-    n_tri = int(rng.choice([1, 2, 3, 7, 20, 60, 150, 400]))
+    n_tri = int(rng.choice([1, 2, 3, 7, 20, 60, 150, 400] + ([3000, 12000, 40000] if big else [])))
     scale = float(rng.choice([0.01, 1.0, 1.0, 1.0, 50.0, 3000.0]))
     V, VN, VT, F = [], [], [], []
 
@@ -166,7 +166,7 @@ def main():
             t_print = time.time()
         d = tempfile.mkdtemp(prefix="trt_fuzz_scene_")
         try:
-            desc, w, h = write_random_scene(d, rng)
+            desc, w, h = write_random_scene(d, rng, big=a.gpu)
             leaf = int(rng.choice([1, 2, 2, 3, 4, 8, 8, 15]))
             builder = str(rng.choice(["sweep", "binned", "auto"] + (["lbvh", "lbvh"] if a.gpu else [])))  # with --gpu: the GPU builder's trees too (leaves of <= 2)
             try:
