@@ -22,7 +22,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sizes = {"back": (257, 131), "veach-mis": (320, 180), "staircase": (192, 108), "soup": (160, 90)}
-    scenes, renderers, alt, scenes_gpu_tree, on_gpu_tree, scenes_leaf8, on_leaf8, scenes_foreign, on_foreign = {}, {}, {}, {}, {}, {}, {}, {}, {}
+    scenes, renderers, alt, scenes_gpu_tree, on_gpu_tree, scenes_leaf8, on_leaf8, scenes_foreign, on_foreign, on_default_no_tail = {}, {}, {}, {}, {}, {}, {}, {}, {}, {}
     for name, (w, h) in sizes.items():
         scenes[name] = T.Scene.named(name, w, h, **({"n": 50000} if name == "soup" else {}))
         renderers[name] = T.Renderer(scenes[name], 0)
@@ -48,8 +48,11 @@ def main():
         # compressed ones), and per-lane traversal instead of the uniform walk for the tiny scene
         os.environ["TRT_NODE_KIND"] = "0"
         os.environ["TRT_TRACE_IMPL"] = "3"
+        os.environ["TRT_TAIL_N"] = "64"  # ... and no early hand-over to k_tail: tiles this small would leave every bounce after the first to it
         alt[name] = T.Renderer(scenes[name], 0)
         del os.environ["TRT_NODE_KIND"], os.environ["TRT_TRACE_IMPL"]
+        on_default_no_tail[name] = T.Renderer(scenes[name], 0)  # the default kernels, all bounces in the queue kernels
+        del os.environ["TRT_TAIL_N"]
     t0 = time.time()
     t_print = t0
     n = 0
@@ -80,7 +83,7 @@ def main():
         if not T.rows_selected(p):
             continue
         pick = rng.random()
-        use = on_gpu_tree if pick < 0.2 else (alt if pick < 0.4 else (on_leaf8 if pick < 0.6 else (on_foreign if pick < 0.75 else renderers)))
+        use = on_gpu_tree if pick < 0.2 else (alt if pick < 0.4 else (on_leaf8 if pick < 0.6 else (on_foreign if pick < 0.7 else (on_default_no_tail if pick < 0.85 else renderers))))
         try:
             img, st = use[name].render(p)
         except T.TrtError as e:
@@ -91,7 +94,7 @@ def main():
         ok = np.array_equal(img, ref) and (st.rays_camera, st.rays_shadow, st.rays_indirect) == (ost.rays_camera, ost.rays_shadow, ost.rays_indirect)
         n += 1
         if not ok:
-            print("MISMATCH", name, "foreign" if use is on_foreign else ("leaf8" if use is on_leaf8 else ("lbvh" if use is on_gpu_tree else ("alt" if use is alt else "default"))), dict(tile=(x0, y0, x1, y1), spp=spp, seed=seed, flags=flags, max_depth=md, rows=rows, mem_budget=budget_b), flush=True)
+            print("MISMATCH", name, "foreign" if use is on_foreign else ("leaf8" if use is on_leaf8 else ("lbvh" if use is on_gpu_tree else ("alt" if use is alt else ("no_tail" if use is on_default_no_tail else "default")))), dict(tile=(x0, y0, x1, y1), spp=spp, seed=seed, flags=flags, max_depth=md, rows=rows, mem_budget=budget_b), flush=True)
             sys.exit(1)
     print(f"fuzz parity: {n} random configurations, all bit-identical to the oracle ({time.time() - t0:.0f} s)")
 

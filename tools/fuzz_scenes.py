@@ -201,7 +201,9 @@ def main():
                         H.set_node_kind(old)
                     results.append((f"device code on the CPU, node kind {nk}", img, rays))
                 if a.gpu:
-                    for env in ({}, {"TRT_NODE_KIND": "0", "TRT_TRACE_IMPL": "3"}, {"TRT_NODE_KIND": "1", "TRT_TRACE_IMPL": "3"}):
+                    # (TRT_TAIL_N=16: images this small would otherwise leave every bounce after the first to k_tail; with it the queue kernels run them all)
+                    for env in ({}, {"TRT_NODE_KIND": "0", "TRT_TRACE_IMPL": "3"}, {"TRT_NODE_KIND": "1", "TRT_TRACE_IMPL": "3"}, {"TRT_TAIL_N": "16"},
+                                {"TRT_NODE_KIND": str(int(rng.integers(0, 2))), "TRT_TRACE_IMPL": "3", "TRT_TAIL_N": "16"}):
                         os.environ.update(env)
                         try:
                             r = T.Renderer(s, 0)
