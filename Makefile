@@ -65,7 +65,7 @@ $(OUT)/tinyrt: $(PKG)/host/main.cpp $(PKG)/host/render.cpp $(HOST_HDR) include/t
 # name=defines, "+" separating the -D options
 # (round 4's k_shade occupancy arms — block sizes 256 / 512 / 640 / 768 at 4, 5 and 6 waves per SIMD — are on record in profiles/r04_ab_shade_tail.txt; what
 # won is in the default build: TRT_SHADE1_* / TRT_SHADEN_* in trt_kernels.h.  shade_old = round 3's configuration for the A/B.)
-VARIANTS := w8=-DTRT_TRACE_MINWAVES=8 short=-DTRT_PROBE_SHORT_RECORDS shade_old=-DTRT_SHADE1_BLOCK=512+-DTRT_SHADE1_WAVES=4+-DTRT_SHADEN_BLOCK=512+-DTRT_SHADEN_WAVES=4
+VARIANTS := w8=-DTRT_TRACE_MINWAVES=8 nt0=-DTRT_NT=0 nt15=-DTRT_NT=15 shade_old=-DTRT_SHADE1_BLOCK=512+-DTRT_SHADE1_WAVES=4+-DTRT_SHADEN_BLOCK=512+-DTRT_SHADEN_WAVES=4
 variants: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(OUT)/variants
 	@for v in $(VARIANTS); do name=$${v%%=*}; defs=$$(echo "$${v#*=}" | tr '+' ' '); \

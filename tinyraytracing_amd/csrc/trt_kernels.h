@@ -187,11 +187,32 @@ struct RaySource {
     TileDesc td;
     uint32_t s0;
 };
+// Queue records are written once by one kernel and read once by the next, far more of them than any cache holds: TRT_NT (bit mask) marks their accesses
+// non-temporal — 1: k_shade's loads, 2: k_shade's stores, 4: the traversal kernels' ray loads, 8: their hit stores.  Measured (profiles/r04_ab_nt.txt, one box,
+// two rounds): 2 shortens k_shade by 3-5 % where it has several queues to feed (veach-mis, soup, the 10 M mesh); 1 + 2 also the shadow kernel of the Cornell
+// box by 3.5 % (22.9 -> 22.1 ms); 4 and 8 change nothing or take that back.  Default 3: +0.5 to +0.8 % rays per second on every workload.
+#ifndef TRT_NT
+#define TRT_NT 3
+#endif
+typedef float trt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 ldNT(const f4* p)
+{
+    const trt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const trt_v4f*>(p));
+    return mk4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stNT(f4* p, f4 v)
+{
+    const trt_v4f q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<trt_v4f*>(p));
+}
+#define TRT_LDQ(bit, ptr) (((TRT_NT) & (bit)) ? ldNT(ptr) : *(ptr))
+#define TRT_STQ(bit, ptr, val) do { if ((TRT_NT) & (bit)) stNT((ptr), (val)); else *(ptr) = (val); } while (0)
+
 template <bool PRIMARY>
 __device__ __forceinline__ void fetchRay(const SceneDev& sc, const RaySource& src, uint32_t i, f4& a, f4& b)
 {
     if (PRIMARY) primaryRay(sc, src.td, src.s0, i, a, b);
-    else { a = src.ra[i]; b = src.rb[i]; }
+    else { a = TRT_LDQ(4, src.ra + i); b = TRT_LDQ(4, src.rb + i); }
 }
 
 // Rays whose result failed the check of traceClosest() (a hit in front of the box of its own leaf; one in ~10^7): the traversal
@@ -225,7 +246,7 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
             float t, un, vn, det;
             if (triTest(sc.tri_isect[best_tri], o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
         }
-        hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
+        TRT_STQ(8, hit + idx, mk4(best_t, u2f((uint32_t)best_tri), u, v));
     } else if (any ? best_tri < 0 : (best_tri >= 0 && (best_flags >> 8) == light_mat)) {
         // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material;
         // TRT_FLAG_FIXED_NEE (`any`): visible iff nothing lies in front of the light sample
@@ -261,7 +282,7 @@ __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 
             float t, un, vn, det;
             if (triTest(T, o, d, t, un, vn, det)) { u = un / det; v = vn / det; }
         }
-        hit[idx] = mk4(best_t, u2f((uint32_t)best_tri), u, v);
+        TRT_STQ(8, hit + idx, mk4(best_t, u2f((uint32_t)best_tri), u, v));
     } else {
         const bool vis = any ? best_tri < 0 : (best_tri >= 0 && (best_flags >> 8) == light_mat);
         f4 w = mk4(0, 0, 0, 0), L = w;
@@ -966,17 +987,7 @@ struct RowsShade {
 // instantiation.  A compile-time choice so that every table access is a plain LDS (ds_read) or global load: behind a
 // run-time choice the pointers are generic, the accesses FLAT, and each of them waits for vmcnt(0) — i.e. for the ray
 // stores issued before it — as well as for the LDS.
-// Performance probe only (make variants, `short`): the weight and throughput records stored as 8 bytes instead of 16 — WRONG images, same
-// instruction stream otherwise — to measure what a record diet of k_shade could buy at most (profiles/r03_ab_oct.txt (8)).
-#ifdef TRT_PROBE_SHORT_RECORDS
-#define TRT_STORE_W(arr, slot, x, y, z) (reinterpret_cast<float2*>(arr)[slot] = make_float2((x), (y) + (z)))
-#define TRT_STORE_BT(arr, slot, v) (reinterpret_cast<float2*>(arr)[slot] = make_float2((v).x + (v).w, (v).y + (v).z))
-#define TRT_LOAD_BT(arr, i, bt) { const float2 q_ = reinterpret_cast<const float2*>(arr)[i]; (bt) = mk4(q_.x, q_.y, q_.y, 0.0f); }
-#else
-#define TRT_STORE_W(arr, slot, x, y, z) ((arr)[slot] = mk4((x), (y), (z), 0.0f))
-#define TRT_STORE_BT(arr, slot, v) ((arr)[slot] = (v))
-#define TRT_LOAD_BT(arr, i, bt) ((bt) = (arr)[i])
-#endif
+// (Round 3's probe `short` — weight and throughput records stored as 8 bytes, wrong images — bought k_shade 3 %: profiles/r03_ab_oct.txt (8).)
 // ONE_LIGHT: the scene has exactly one light (the loop over the lights' stages is empty at compile time).  BLOCK threads, WAVES per SIMD asked of the compiler.
 template <uint32_t TABS, bool ONE_LIGHT, int BLOCK = (ONE_LIGHT ? TRT_SHADE1_BLOCK : TRT_SHADEN_BLOCK), int WAVES = (ONE_LIGHT ? TRT_SHADE1_WAVES : TRT_SHADEN_WAVES)>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_shade(SceneDev sc, ShadeArgs A)
@@ -1014,8 +1025,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_shade(SceneDev sc, ShadeArgs A
     auto loadTile = [&](uint32_t i, f4& hit4, f4& ra, f4& rb, f4& bt) {
         hit4 = mk4(TRT_INF, u2f(0xFFFFFFFFu), 0.0f, 0.0f); ra = mk4(0, 0, 0, 0); rb = ra; bt = mk4(1.0f, 1.0f, 1.0f, 0.0f);
         if (i < A.n) {
-            hit4 = A.hit[i];
-            if (!A.primary) { ra = A.qin.ra[i]; rb = A.qin.rb[i]; TRT_LOAD_BT(A.qin.bt, i, bt); }
+            hit4 = TRT_LDQ(1, A.hit + i);
+            if (!A.primary) { ra = TRT_LDQ(1, A.qin.ra + i); rb = TRT_LDQ(1, A.qin.rb + i); bt = TRT_LDQ(1, A.qin.bt + i); }
         }
     };
 #if TRT_SHADE_PIPE
@@ -1092,9 +1103,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_shade(SceneDev sc, ShadeArgs A
             if (pend_emit) {
                 const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
                 const f3 so = rayOrigin(c, pend_wo);  // Q6: the hit point itself unless TRT_FLAG_RAY_OFFSET
-                A.sq[pend_li].sa[slot] = mk4(so.x, so.y, so.z, pend_wo.x);
-                A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
-                TRT_STORE_W(A.sq[pend_li].sw, slot, pend_w.x, pend_w.y, pend_w.z);
+                TRT_STQ(2, A.sq[pend_li].sa + slot, mk4(so.x, so.y, so.z, pend_wo.x));
+                TRT_STQ(2, A.sq[pend_li].sb + slot, mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax));
+                TRT_STQ(2, A.sq[pend_li].sw + slot, mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f));
             }
             pend_s = s; pend_emit = emit; pend_rank = rank; pend_li = li; pend_wo = wo; pend_w = c.beta * contrib; pend_tmax = t_max;
         }
@@ -1121,9 +1132,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_shade(SceneDev sc, ShadeArgs A
         if (pend_emit) {  // the last light but one (its base was published before the barrier above)
             const uint32_t slot = pend_s[TRT_SHADE_BLOCK / 64] + pend_s[threadIdx.x >> 6] + pend_rank;
             const f3 so = rayOrigin(c, pend_wo);
-            A.sq[pend_li].sa[slot] = mk4(so.x, so.y, so.z, pend_wo.x);
-            A.sq[pend_li].sb[slot] = mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax);
-            TRT_STORE_W(A.sq[pend_li].sw, slot, pend_w.x, pend_w.y, pend_w.z);
+            TRT_STQ(2, A.sq[pend_li].sa + slot, mk4(so.x, so.y, so.z, pend_wo.x));
+            TRT_STQ(2, A.sq[pend_li].sb + slot, mk4(pend_wo.y, pend_wo.z, u2f(c.pid), pend_tmax));
+            TRT_STQ(2, A.sq[pend_li].sw + slot, mk4(pend_w.x, pend_w.y, pend_w.z, 0.0f));
         }
         f4 nra = mk4(0, 0, 0, 0), nrb = nra, nbt = nra;
         if (emit_next) shadeNextFinish(c, plan, nra, nrb, nbt);
@@ -1135,15 +1146,15 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_shade(SceneDev sc, ShadeArgs A
         if (emit_s) {
             const uint32_t slot = s2[2 * (TRT_SHADE_BLOCK / 64) + 1] + s2[TRT_SHADE_BLOCK / 64 + 1 + (threadIdx.x >> 6)] + rank_s;
             const f3 so = rayOrigin(c, wo_s);
-            A.sq[nl - 1u].sa[slot] = mk4(so.x, so.y, so.z, wo_s.x);
-            A.sq[nl - 1u].sb[slot] = mk4(wo_s.y, wo_s.z, u2f(c.pid), tmax_s);
-            TRT_STORE_W(A.sq[nl - 1u].sw, slot, w_s.x, w_s.y, w_s.z);
+            TRT_STQ(2, A.sq[nl - 1u].sa + slot, mk4(so.x, so.y, so.z, wo_s.x));
+            TRT_STQ(2, A.sq[nl - 1u].sb + slot, mk4(wo_s.y, wo_s.z, u2f(c.pid), tmax_s));
+            TRT_STQ(2, A.sq[nl - 1u].sw + slot, mk4(w_s.x, w_s.y, w_s.z, 0.0f));
         }
         if (emit_next) {
             const uint32_t slot = s2[TRT_SHADE_BLOCK / 64] + s2[threadIdx.x >> 6] + rank_next;
-            A.qout.ra[slot] = nra;
-            A.qout.rb[slot] = nrb;
-            TRT_STORE_BT(A.qout.bt, slot, nbt);
+            TRT_STQ(2, A.qout.ra + slot, nra);
+            TRT_STQ(2, A.qout.rb + slot, nrb);
+            TRT_STQ(2, A.qout.bt + slot, nbt);
         }
     }
     __syncthreads();
