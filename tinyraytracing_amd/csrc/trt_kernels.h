@@ -188,9 +188,11 @@ struct RaySource {
     uint32_t s0;
 };
 // Queue records are written once by one kernel and read once by the next, far more of them than any cache holds: TRT_NT (bit mask) marks their accesses
-// non-temporal — 1: k_shade's loads, 2: k_shade's stores, 4: the traversal kernels' ray loads, 8: their hit stores.  Measured (profiles/r04_ab_nt.txt, one box,
+// non-temporal — 1: k_shade's loads, 2: k_shade's stores, 4: the traversal kernels' ray loads, 8: their hit stores, 16: the shadow kernels' weight loads,
+// 32: their read-modify-write of the radiance sums.  Measured (profiles/r04_ab_nt.txt, one box,
 // two rounds): 2 shortens k_shade by 3-5 % where it has several queues to feed (veach-mis, soup, the 10 M mesh); 1 + 2 also the shadow kernel of the Cornell
-// box by 3.5 % (22.9 -> 22.1 ms); 4 and 8 change nothing or take that back.  Default 3: +0.5 to +0.8 % rays per second on every workload.
+// box by 3.5 % (22.9 -> 22.1 ms); 4 and 8 change nothing or take that back; 16 changes nothing; 32 costs the Cornell box's shadow kernel 11 % (the sums ARE reused: one per path and light).
+// Default 3: +0.5 to +0.8 % rays per second on every workload.
 #ifndef TRT_NT
 #define TRT_NT 3
 #endif
@@ -250,10 +252,10 @@ __device__ __forceinline__ void storeResult(const SceneDev& sc, f3 o, f3 d, floa
     } else if (any ? best_tri < 0 : (best_tri >= 0 && (best_flags >> 8) == light_mat)) {
         // pathTracing.cpp:55-58 (Q5): visible iff the CLOSEST hit carries the light's material;
         // TRT_FLAG_FIXED_NEE (`any`): visible iff nothing lies in front of the light sample
-        const f4 w = sw[idx];
-        f4 L = Lacc[pid];
+        const f4 w = TRT_LDQ(16, sw + idx);
+        f4 L = TRT_LDQ(32, Lacc + pid);
         L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
-        Lacc[pid] = L;
+        TRT_STQ(32, Lacc + pid, L);
     }
 }
 
@@ -286,13 +288,13 @@ __device__ __forceinline__ bool checkedStore(const SceneDev& sc, f3 o, f3 d, f3 
     } else {
         const bool vis = any ? best_tri < 0 : (best_tri >= 0 && (best_flags >> 8) == light_mat);
         f4 w = mk4(0, 0, 0, 0), L = w;
-        if (vis) { w = sw[idx]; L = Lacc[pid]; }
+        if (vis) { w = TRT_LDQ(16, sw + idx); L = TRT_LDQ(32, Lacc + pid); }
         float e;
         const bool pass = boxTest(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, o, inv, e);
         if (special || (best_tri >= 0 && ((OCT && !pass) || best_t < trt_leaf_floor(e, sc.leaf_alpha)))) return true;
         if (vis) {
             L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
-            Lacc[pid] = L;
+            TRT_STQ(32, Lacc + pid, L);
         }
     }
     return false;
