@@ -397,8 +397,8 @@ __device__ __forceinline__ void uniformWalkImpl(const SceneDev& sc, f3 o, f3 d, 
     }
     flush();
 }
-// One vote per ray; the second instantiation runs only in a wave that holds a ray with a zero direction component (inside the node loop even a wave-uniform
-// branch cost the headline's traversal 4 %).
+// The walk for k_tail (a few thousand paths, latency-bound; not the queue kernels, which park such rays: traceQueueUniform): one vote per ray, and the
+// instantiation with the literal test only in a wave that holds a ray with a zero direction component.
 template <bool COUNT, int STRIDE = TRT_TRACE_BLOCK>
 __device__ __forceinline__ void uniformWalk(const SceneDev& sc, f3 o, f3 d, bool valid, f4* __restrict__ my_pend, float& best_t, int32_t& best_tri,
                                             uint32_t& best_flags, uint32_t& n_inner, uint32_t& n_tri)
